@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's benchmark contract for the escape-time hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one frame of BASELINE.json's metric configuration:
+Mandelbrot 4096x4096, max_iter 1024, fp64, default viewport (configs[1], "C2"), output planes
+resident in HBM.  metric = Mpixels/s (whole job).  At N > 1 the SAME frame is cut into row strips
+dealt round-robin to the ranks, each rank renders its strips and the strips are gathered to rank 0
+over RCCL (strong scaling; gather of frame n overlaps render of frame n+1).
+
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  roofline       the metric's own roofline ("achieved HBM GB/s vs peak"): algorithmic bytes
+                 16 B/pixel (RGBA f32, write-once) / average kernel time measured with HIP events
+                 on the launch stream over the timed region; traffic = PMC WRITE_SIZE+FETCH_SIZE per
+                 launch from the committed rocprofv3 pass (profiles/), or null.
+  roofline_valu  the bound that actually limits the kernel: fp64 VALU issue.
+                 achieved = 8 flop x executed iterations (counted exactly from the iter plane) / kernel
+                 time; peak = 39.3 T fp64 op/s (78.6 TFLOP/s FMA-counted / 2: the loop cannot contract).
+  cpu_baseline   the CPU oracle (oracle/fr_oracle.c, OpenMP, all host cores) timed on a bounded sample
+                 of the same frame, rank 0, N = 1 only.  kind "port": the reference has no CPU path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (fractal, precision, W, H, state kwargs)
+    "c2": dict(desc="C2 mandelbrot 4096x4096 max_iter=1024 fp64 default viewport (center -0.5,0 zoom 3.0)",
+               fractal="Mandelbrot", precision="F64", W=4096, H=4096, state=dict(max_iterations=1024)),
+    "c2_reset": dict(desc="mandelbrot 4096x4096 max_iter=1024 fp64 reset() viewport (zoom 1.5)",
+                     fractal="Mandelbrot", precision="F64", W=4096, H=4096, state=dict(max_iterations=1024, zoom=1.5)),
+    "c3": dict(desc="C3 julia c=-0.8+0.156i 4096x4096 max_iter=2048 fp32 centre (0,0) zoom 3.0",
+               fractal="JuliaSet", precision="F32", W=4096, H=4096,
+               state=dict(max_iterations=2048, center_x=0.0, center_y=0.0, julia_c_real=-0.8, julia_c_imag=0.156)),
+    "c4": dict(desc="C4 deep-zoom mandelbrot 8192x8192 max_iter=16384 fp64 seahorse zoom 1e-6",
+               fractal="Mandelbrot", precision="F64", W=8192, H=8192,
+               state=dict(max_iterations=16384, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-6)),
+    "c5": dict(desc="C5 mandelbrot 8192x8192 max_iter=4096 fp64 seahorse zoom 0.008 (one .franim keyframe view)",
+               fractal="Mandelbrot", precision="F64", W=8192, H=8192,
+               state=dict(max_iterations=4096, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.008)),
+}
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s vector fp64 counts FMA as 2; contraction-off loop issues 1 op/slot
+FP32_VALU_PEAK_TOPS = 78.6     # 157.3 TFLOP/s / 2
+
+
+def cpu_baseline(workload: dict, budget_rows: int = 1024) -> dict:
+    """Oracle timed on the host cores on evenly spaced row bands of the same frame."""
+    from oracle import oracle as O
+    O.build()
+    w = workload
+    st = w["state"]
+    p = O.OracleParams(fractal=0 if w["fractal"] == "Mandelbrot" else 1, precision=1 if w["precision"] == "F64" else 0,
+                       **{("max_iterations" if k == "max_iterations" else k): v for k, v in st.items()})
+    W, H = w["W"], w["H"]
+    bands, band_rows = 16, max(1, budget_rows // 16)
+    threads = O.max_threads()
+    O.render(p, W, H, y0=0, y1=2, threads=threads, planes=False)          # warm the thread pool
+    t0 = time.perf_counter()
+    px = 0
+    for b in range(bands):
+        y0 = (H // bands) * b + (H // bands - band_rows) // 2
+        O.render(p, W, H, y0=y0, y1=y0 + band_rows, threads=threads, planes=False)
+        px += band_rows * W
+    dt = time.perf_counter() - t0
+    cpu = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "sample": f"{bands} evenly spaced bands of {band_rows} rows ({px} of {W*H} pixels) of the same frame, "
+                      f"oracle/fr_oracle.c -O2 -ffp-contract=off, OpenMP schedule(dynamic,1), {dt:.1f} s",
+            "cpu": cpu, "nproc": os.cpu_count()}
+
+
+def pmc_traffic(workload_name: str):
+    """HBM bytes per launch from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        e = d.get(workload_name)
+        return e.get("hbm_bytes_per_launch") if e else None
+    except (OSError, ValueError):
+        return None
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wg-per-cu", type=int, default=0)
+    ap.add_argument("--run-max", type=int, default=0)
+    ap.add_argument("--shape", type=int, default=0)
+    ap.add_argument("--rows-per-strip", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import fractalrenderer_amd as fr
+    from fractalrenderer_amd.distributed import StripGather
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = WORKLOADS[args.workload]
+    W, H = w["W"], w["H"]
+    state = fr.FractalState(**w["state"])
+    ftype = fr.FractalType[w["fractal"]]
+    prec = fr.Precision[w["precision"]]
+    r = fr.Renderer(local_rank)
+    r.set_tuning(args.wg_per_cu, args.run_max, args.shape)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kernel_ms = None
+    executed = None
+    if world == 1:
+        rgba = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+        # exact executed-iteration count of this frame from the iter plane (outside the timed region)
+        it = torch.empty((H, W), dtype=torch.int32, device=dev)
+        r.render(state, W, H, fractal_type=ftype, precision=prec, rgba=rgba, iter=it)
+        mi = state.max_iterations
+        executed = int(torch.where(it < mi, it.to(torch.int64) + 1, torch.full_like(it, mi, dtype=torch.int64)).sum())
+        del it
+        stream = torch.cuda.current_stream()
+        h = stream.cuda_stream
+
+        def step(_k):
+            r.render(state, W, H, fractal_type=ftype, precision=prec, rgba=rgba, sync=False, stream=h)
+
+        for k in range(args.warmup):
+            step(k)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)                       # HIP events on the launch stream, over the timed region
+        for k in range(args.steps):
+            step(k)
+        ev1.record(stream)
+        barrier()
+        dt = time.perf_counter() - t0
+        kernel_ms = ev0.elapsed_time(ev1) / args.steps
+        last_ms = r.last_kernel_ms()             # the library's own event pair around the last launch
+    else:
+        sg = StripGather(W, H, 4, torch.float32, dev, rows_per_strip=args.rows_per_strip)
+
+        def render_fn(shard, out, _frame):
+            r.render(state, W, H, fractal_type=ftype, precision=prec, rgba=out, shard=shard, sync=False,
+                     stream=torch.cuda.current_stream().cuda_stream)
+
+        for k in range(args.warmup):
+            sg.submit(render_fn, k)
+        sg.drain()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            sg.submit(render_fn, k)
+        sg.drain()
+        barrier()
+        dt = time.perf_counter() - t0
+        last_ms = r.last_kernel_ms()
+
+    # MAX over ranks
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        mpx = args.steps * W * H / dt / 1e6
+        out = {
+            "metric": "Mpixels/s at 4096x4096 max_iter=1024; achieved HBM GB/s vs peak" if args.workload == "c2"
+                      else f"Mpixels/s ({args.workload})",
+            "value": round(mpx, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64" if prec == fr.Precision.F64 else "f32", "data": "synthetic",
+            "config": {"workload": w["desc"], "output": "RGBA f32 linear colour, 16 B/pixel, resident in HBM",
+                       "parallelism": (f"row strips of {sg.R} rows round-robin over {world} GPUs + RCCL gather to rank 0, "
+                                       "double-buffered" if world > 1 else "1 GPU, persistent tile queue"),
+                       "compute_units": r.compute_units},
+        }
+        if world == 1:
+            bytes_per_launch = 16 * W * H
+            gbs = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.workload),
+                               "kernel_ms": round(kernel_ms, 4), "kernel_ms_last_launch": round(last_ms, 4),
+                               "note": "the metric's HBM roofline; the kernel is fp64-VALU-bound, see roofline_valu"}
+            peak = FP64_VALU_PEAK_TOPS if prec == fr.Precision.F64 else FP32_VALU_PEAK_TOPS
+            tops = 8.0 * executed / (kernel_ms * 1e-3) / 1e12
+            out["roofline_valu"] = {"bound": "valu_" + out["dtype"], "achieved": round(tops, 3), "peak": peak,
+                                    "unit": "Tflop/s (8 flop per executed iteration, no FMA credit)",
+                                    "frac": round(tops / peak, 4), "executed_iterations": executed,
+                                    "mean_iterations_per_pixel": round(executed / (W * H), 2)}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""ctypes binding of libfractalrenderer_amd.so (include/fractalrenderer_amd.h).
+
+The shared library is the product; this module only declares its C ABI to Python.
+There is no fallback of any kind: if the library is missing, import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfractalrenderer_amd.so")
+
+FR_OK = 0
+FR_ERR_INVALID_ARG = -1
+FR_ERR_NO_DEVICE = -2
+FR_ERR_HIP = -3
+FR_ERR_UNSUPPORTED = -4
+FR_ERR_IO = -5
+FR_ERR_PARSE = -6
+FR_ERR_NOMEM = -7
+
+FR_MEM_DEVICE = 0
+FR_MEM_HOST = 1
+
+FR_PRECISION_F32 = 0
+FR_PRECISION_F64 = 1
+
+FR_FLAG_POST_CHAIN = 0x1
+
+
+class fr_params(C.Structure):
+    _fields_ = [
+        ("fractal_type", C.c_int32), ("precision", C.c_int32),
+        ("center_x", C.c_double), ("center_y", C.c_double), ("zoom", C.c_double),
+        ("max_iterations", C.c_int32), ("bailout", C.c_float),
+        ("julia_c_real", C.c_double), ("julia_c_imag", C.c_double),
+        ("antialiasing_samples", C.c_int32), ("palette_mode", C.c_int32),
+        ("color_offset", C.c_float), ("color_scale", C.c_float),
+        ("interior_style", C.c_int32),
+        ("orbit_trap_enabled", C.c_int32), ("orbit_trap_radius", C.c_float),
+        ("stripe_enabled", C.c_int32), ("stripe_density", C.c_float),
+        ("color_brightness", C.c_float), ("color_saturation", C.c_float), ("color_contrast", C.c_float),
+        ("flags", C.c_uint32),
+    ]
+
+
+class fr_output(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("nu", C.c_void_p), ("iter", C.c_void_p), ("memory", C.c_int32)]
+
+
+class fr_shard(C.Structure):
+    _fields_ = [("part", C.c_uint32), ("nparts", C.c_uint32), ("rows_per_strip", C.c_uint32)]
+
+
+class fr_anim_info(C.Structure):
+    _fields_ = [("duration", C.c_float), ("loop", C.c_int32), ("target_fps", C.c_int32),
+                ("export_width", C.c_int32), ("export_height", C.c_int32), ("keyframe_count", C.c_int32)]
+
+
+class fr_keyframe(C.Structure):
+    _fields_ = [("time", C.c_float), ("interp_type", C.c_int32), ("state", fr_params)]
+
+
+# every symbol include/fractalrenderer_amd.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+SIGNATURES = {
+    "fr_params_default": (C.c_int, [_P(fr_params)]),
+    "fr_params_reset": (C.c_int, [_P(fr_params)]),
+    "fr_params_validate": (C.c_int, [_P(fr_params), C.c_uint32, C.c_uint32]),
+    "fr_pack_push_constants": (C.c_int, [_P(fr_params), _P(C.c_float)]),
+    "fr_ctx_create": (C.c_int, [C.c_int, _P(C.c_void_p)]),
+    "fr_ctx_destroy": (None, [C.c_void_p]),
+    "fr_shard_rows": (C.c_uint32, [_P(fr_shard), C.c_uint32]),
+    "fr_shard_global_row": (C.c_uint32, [_P(fr_shard), C.c_uint32, C.c_uint32]),
+    "fr_render": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, _P(fr_output)]),
+    "fr_render_shard": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, _P(fr_shard), _P(fr_output)]),
+    "fr_render_shard_async": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, _P(fr_shard),
+                                        _P(fr_output), C.c_void_p]),
+    "fr_ctx_last_kernel_ms": (C.c_float, [C.c_void_p]),
+    "fr_ctx_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "fr_ctx_compute_units": (C.c_int, [C.c_void_p]),
+    "fr_export_rgb8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32]),
+    "fr_anim_load": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),
+    "fr_anim_parse": (C.c_int, [C.c_char_p, C.c_size_t, _P(C.c_void_p)]),
+    "fr_anim_free": (None, [C.c_void_p]),
+    "fr_anim_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "fr_anim_get_info": (C.c_int, [C.c_void_p, _P(fr_anim_info)]),
+    "fr_anim_get_keyframe": (C.c_int, [C.c_void_p, C.c_int32, _P(fr_keyframe)]),
+    "fr_anim_name": (C.c_char_p, [C.c_void_p]),
+    "fr_anim_description": (C.c_char_p, [C.c_void_p]),
+    "fr_anim_create": (C.c_int, [_P(C.c_void_p)]),
+    "fr_anim_add_keyframe": (C.c_int, [C.c_void_p, C.c_float, _P(fr_params), C.c_int32]),
+    "fr_anim_state_at": (C.c_int, [C.c_void_p, C.c_float, _P(fr_params), _P(fr_params)]),
+    "fr_anim_frame_count": (C.c_int32, [C.c_void_p]),
+    "fr_anim_frame_time": (C.c_float, [C.c_void_p, C.c_int32]),
+    "fr_reference_orbit": (C.c_int, [C.c_double, C.c_double, C.c_int32, C.c_void_p, _P(C.c_int32)]),
+    "fr_last_error": (C.c_char_p, []),
+    "fr_status_string": (C.c_char_p, [C.c_int]),
+    "fr_version": (None, [_P(C.c_int), _P(C.c_int)]),
+}
+
+
+class FractalRendererError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"fractalrenderer_amd: status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the C-ABI library.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C fractalrenderer_amd/csrc`. There is no Python/CPU fallback for the render path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> int:
+    if status < 0:
+        raise FractalRendererError(status, lib().fr_last_error().decode("utf-8", "replace"))
+    return status

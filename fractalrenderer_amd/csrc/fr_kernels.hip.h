@@ -1,0 +1,559 @@
+/*
+ * fr_kernels.hip.h -- hand-written CDNA4 (gfx950) escape-time kernels.
+ *
+ * What is computed is the per-pixel loop of shaders/mandelbrot.comp:147-208 and
+ * shaders/julia.comp:216-249 (z <- z^2 + c, update-then-test, smooth iteration count,
+ * palette), in fp32 (what the reference does) or fp64.  How it is computed is
+ * MI355X-first and shares nothing with the reference's 16x16-workgroup GLSL dispatch:
+ *
+ *   - one wavefront lane per pixel; a wave owns a "sub-tile" of 64 pixels
+ *     (8x8, 16x4 or 64x1 -- every lane row is a whole number of 128-byte lines of the
+ *     row-major RGBA-f32 frame, so stores are full-line coalesced);
+ *   - a PERSISTENT grid (CUs x k workgroups) pulls runs of sub-tiles from a tile queue
+ *     sharded per XCD (8 heads, 128 B apart), with guided run lengths (long runs first,
+ *     single sub-tiles at the end) and stealing from the other XCDs' shards when the
+ *     home shard is dry; the next dequeue is issued before the current run is iterated,
+ *     so its latency hides under the arithmetic;
+ *   - the iteration index is wave-uniform and lives in SGPRs; a lane that escapes
+ *     records (i, |z|^2) and is parked at the fixed point z = 0, c = 0, so no per-lane
+ *     "active" predicate exists in the loop; the wave leaves the loop as soon as the
+ *     ballot of escaped lanes is full (wave-uniform early-out);
+ *   - the arithmetic is the reference's, one rounding per operation, NO contraction of
+ *     the as-written a*b+c (file is built with -ffp-contract=off).  Where an fma is
+ *     written explicitly it multiplies by an exact power of two, which rounds exactly
+ *     like the as-written two-operation form (see "scaled-imaginary form" below);
+ *   - the palette knot table and the viewport constants are staged once per workgroup
+ *     into LDS; every lane reads them from there (broadcast ds_reads).
+ *
+ * There is no dense contraction in this path: no MFMA.  The bound is fp64 (fp32) VALU
+ * issue; HBM traffic is the write-once 16 B/pixel output.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fr_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace fr {
+
+constexpr int kWave = 64;
+constexpr int kBlockThreads = 256;
+constexpr int kShards = 8;               /* one queue head per XCD                        */
+constexpr int kShardStrideWords = 32;    /* 128 B between heads                            */
+constexpr int kShardBlock = 16;          /* sub-tiles are dealt to shards in blocks of 16  */
+constexpr int kFastBlock = 16;           /* iterations per unchecked block                 */
+
+/* Kernel argument block (passed by value; lands in SGPRs / the scalar cache). */
+struct LaunchArgs {
+    /* viewport -- FractalState fields, src/fractal_state.h:18-21,29-30,36 */
+    double center_x, center_y, zoom;
+    double julia_cx, julia_cy;
+    double log_bailout;          /* log(bailout) in the kernel's precision, computed on the host */
+    float  bailout;
+    int32_t max_iter;
+    int32_t W, H;                /* whole frame                                  */
+    int32_t rows_local;          /* rows this part renders                       */
+    int32_t part, nparts, rows_per_strip;
+    int32_t aa;
+    /* colouring */
+    int32_t palette_mode;
+    float color_offset, color_scale;
+    int32_t interior_style;
+    int32_t trap_enabled; float trap_radius;
+    int32_t stripe_enabled; float stripe_density;
+    float brightness, saturation, contrast;
+    uint32_t flags;
+    int32_t fast_ok;             /* escape is absorbing for every lane (see kernel) */
+    /* outputs */
+    float4* rgba;
+    void* nu;
+    int32_t* iter;
+    /* tile queue */
+    uint32_t* queue;             /* kShards heads, kShardStrideWords apart, zeroed per launch */
+    uint32_t n_sub;              /* total sub-tiles                               */
+    uint32_t nsx;                /* sub-tiles per sub-tile row                    */
+    uint32_t shard_len[kShards]; /* shard-local index space size                  */
+    uint32_t run_shift;          /* run length = clamp(remaining >> run_shift, 1, run_max) */
+    uint32_t run_max;
+    fr_palette_table pal;
+};
+
+/* What one workgroup keeps in LDS: the palette knot table and the viewport constants. */
+struct LdsBlock {
+    fr_palette_table pal;
+    double center_x, center_y, zoom, julia_cx, julia_cy, log_bailout;
+    float bailout, color_offset, color_scale, trap_radius, stripe_density;
+    float brightness, saturation, contrast;
+    int32_t max_iter, W, H, aa;
+};
+
+template <typename T> struct Real;
+template <> struct Real<double> {
+    static __device__ __forceinline__ double log(double x) { return ::log(x); }
+    static __device__ __forceinline__ double floor(double x) { return ::floor(x); }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
+    static __device__ __forceinline__ double fmin(double a, double b) { return ::fmin(a, b); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static constexpr double ln2() { return 0.693147180559945309417232121458; }
+};
+template <> struct Real<float> {
+    static __device__ __forceinline__ float log(float x) { return ::logf(x); }
+    static __device__ __forceinline__ float floor(float x) { return ::floorf(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+    static __device__ __forceinline__ float fabs(float x) { return ::fabsf(x); }
+    static __device__ __forceinline__ float fmin(float a, float b) { return ::fminf(a, b); }
+    static __device__ __forceinline__ float atan2(float y, float x) { return ::atan2f(y, x); }
+    static __device__ __forceinline__ float sin(float x) { return ::sinf(x); }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static constexpr float ln2() { return 0.693147180559945309417232121458f; }
+};
+
+/* ---- colour stage (float, as the shaders) ---------------------------------------------- */
+
+__device__ __forceinline__ float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+
+/* get_palette_color for u = fract(t) already taken (shaders/mandelbrot.comp:129-141,
+ * shaders/julia.comp:162-181), evaluated from the LDS knot table. */
+__device__ __forceinline__ void palette_eval(const fr_palette_table& pal, float u, float rgb[3])
+{
+    const int warp = pal.warp;
+    if (warp == FR_WARP_GRAY) { rgb[0] = rgb[1] = rgb[2] = u; return; }
+    float w = u;
+    if (warp == FR_WARP_POW) {
+        w = powf(u, pal.warp_exp);
+    } else if (warp == FR_WARP_SMOOTHSTEP) {
+        float s = clamp01((u - 0.0f) / (1.0f - 0.0f));
+        w = s * s * (3.0f - 2.0f * s);
+    }
+    /* cascade "if (w < b1) .. else if (w < b2) .." == count of break points <= w */
+    int seg = 0;
+    const int nseg = pal.nseg;
+    for (int k = 1; k < 5; ++k) seg += (k < nseg && !(w < pal.seg_lo[k])) ? 1 : 0;
+    if (pal.last_const && seg == nseg - 1) {
+        rgb[0] = pal.knot[seg][0]; rgb[1] = pal.knot[seg][1]; rgb[2] = pal.knot[seg][2];
+        return;
+    }
+    const float d = w - pal.seg_lo[seg];
+    const float k = pal.seg_div[seg] ? d / pal.seg_k[seg] : d * pal.seg_k[seg];
+    const float* a = pal.knot[seg];
+    const float* b = pal.knot[seg + 1];
+    for (int c = 0; c < 3; ++c) rgb[c] = a[c] * (1.0f - k) + b[c] * k;   /* GLSL mix */
+}
+
+__device__ __forceinline__ float aces(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;   /* shaders/mandelbrot.comp:38-45 */
+    return clamp01((x * (a * x + b)) / (x * (c * x + d) + e));
+}
+
+/* enhance_color -> aces_tonemap -> gamma, shaders/mandelbrot.comp:48-54,233-235;
+ * Julia's floors shaders/julia.comp:319-322 */
+__device__ __forceinline__ void post_chain(float rgb[3], float brightness, float saturation,
+                                           float contrast, bool julia)
+{
+    if (julia) {
+        brightness = fmaxf(brightness, 0.1f);
+        saturation = fmaxf(saturation, 0.0f);
+        contrast = fmaxf(contrast, 0.1f);
+    }
+    float c[3];
+    for (int k = 0; k < 3; ++k) c[k] = rgb[k] * brightness;
+    for (int k = 0; k < 3; ++k) c[k] = (c[k] - 0.5f) * contrast + 0.5f;
+    const float gray = c[0] * 0.299f + c[1] * 0.587f + c[2] * 0.114f;
+    for (int k = 0; k < 3; ++k) c[k] = clamp01(gray * (1.0f - saturation) + c[k] * saturation);
+    for (int k = 0; k < 3; ++k) rgb[k] = powf(aces(c[k]), 1.0f / 2.2f);
+}
+
+/* ---- XCD id ------------------------------------------------------------------------------ */
+__device__ __forceinline__ uint32_t xcc_id()
+{
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;      /* speed hint only: picks the home shard, never correctness */
+}
+
+/* ---- one escape-time run over a wave's 64 samples -------------------------------------------
+ *
+ * Scaled-imaginary form.  State per lane: X = Re z, Yd = 2*Im z, cx, cyd = 2*Im c,
+ * x2 = X*X, y2d = Yd*Yd (= 4*(Im z)^2).  One update:
+ *     p   = X * Yd                 == round(2*zx*zy)            (as-written  2.0*z.x*z.y)
+ *     t   = fma(-0.25, y2d, x2)    == round(zx*zx - zy*zy)      (y2d/4 is exact)
+ *     X'  = t + cx                 == round(t + cx)
+ *     Yd' = fma(2, p, cyd)         == 2*round(p + cy)           (scaling by 2 commutes with rounding)
+ *     x2' = X'*X' ; y2d' = Yd'*Yd'
+ *     r2  = fma(0.25, y2d', x2')   == round(zx'^2 + zy'^2)      (dot(z,z))
+ * i.e. 7 VALU ops instead of the as-written 9 (2*zx, zx*zy, zx*zx, zy*zy, -, +cx, +cy, and
+ * the dot's add), each value bit-identical to the as-written one barring denormal products
+ * (|Im z| < 1e-154), which cannot influence an escape.
+ *
+ * Unchecked blocks.  When escape is absorbing (fast_ok: bailout^2 >= 4.5 and |c| <= bailout
+ * for every live lane, so |z| > bailout implies |z'| >= |z|(|z|-1) > 1.12|z|) the wave runs
+ * kFastBlock updates without computing r2 or testing, then tests once: a lane that escaped
+ * inside the block is still escaped (or inf/NaN) at its end.  If any did, the block is
+ * rolled back to its snapshot and replayed with per-iteration tests, which reproduces the
+ * exact escape index and |z|^2.  The wave stays in tested mode until a whole block passes
+ * with no escape.
+ */
+template <typename T>
+struct Orbit {
+    T X, Yd, cx, cyd, x2, y2d;
+};
+
+template <typename T>
+__device__ __forceinline__ void orbit_step(Orbit<T>& o)
+{
+    const T p = o.X * o.Yd;
+    const T t = Real<T>::fma(T(-0.25), o.y2d, o.x2);
+    o.X = t + o.cx;
+    o.Yd = Real<T>::fma(T(2), p, o.cyd);
+    o.x2 = o.X * o.X;
+    o.y2d = o.Yd * o.Yd;
+}
+
+template <typename T>
+__device__ __forceinline__ T orbit_r2(const Orbit<T>& o)
+{
+    return Real<T>::fma(T(0.25), o.y2d, o.x2);
+}
+
+/* Runs the wave's 64 orbits to completion.  esc_i: escape index (max_iter if never),
+ * esc_r2: |z|^2 at escape.  done_in: lanes that must not run (outside the frame). */
+template <typename T>
+__device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int max_iter,
+                                           const bool fast_ok, const uint64_t done_in,
+                                           int& esc_i, T& esc_r2)
+{
+    esc_i = max_iter;
+    esc_r2 = T(0);
+    uint64_t done = done_in;
+    int i = 0;                       /* wave-uniform: SGPR */
+    bool fast = false;
+
+    while (i < max_iter) {
+        if (done == ~0ull) break;    /* every lane escaped: wave-uniform early-out */
+        const int left = max_iter - i;
+        if (fast && left >= kFastBlock) {
+            const Orbit<T> snap = o;
+#pragma unroll
+            for (int k = 0; k < kFastBlock; ++k) orbit_step(o);
+            const T r2 = orbit_r2(o);
+            const bool bad = !(r2 <= B2);
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) { i += kFastBlock; continue; }
+            o = snap;                /* roll back, replay tested */
+            fast = false;
+        }
+        /* tested block */
+        const int n = left < kFastBlock ? left : kFastBlock;
+        bool any_escape = false;
+        for (int k = 0; k < n; ++k) {
+            orbit_step(o);
+            const T r2 = orbit_r2(o);
+            const bool e = r2 > B2;
+            const uint64_t em = __builtin_amdgcn_ballot_w64(e);
+            if (em != 0ull) {
+                if (e) {
+                    esc_i = i + k;
+                    esc_r2 = r2;
+                    /* park at the fixed point z = 0 of c = 0: never "escapes" again */
+                    o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                }
+                done |= em;
+                any_escape = true;
+                if (done == ~0ull) return;
+            }
+        }
+        i += n;
+        fast = fast_ok && !any_escape;
+    }
+}
+
+/* As-written form with the reference's 3-way orbit trap (shaders/mandelbrot.comp:157-170):
+ * used when orbit_trap / stripes / interior_style 2 need z itself or min_trap. */
+template <typename T>
+__device__ __forceinline__ void escape_run_effects(T& zx, T& zy, const T cx, const T cy, const T B2,
+                                                   const int max_iter, const uint64_t done_in,
+                                                   int& esc_i, T& esc_zx, T& esc_zy, T& min_trap)
+{
+    esc_i = max_iter;
+    min_trap = T(1e20);
+    bool live = true;
+    uint64_t done = done_in;
+    for (int i = 0; i < max_iter; ++i) {
+        if (done == ~0ull) break;
+        const T x = zx * zx - zy * zy + cx;
+        const T y = T(2) * zx * zy + cy;
+        if (live) {
+            zx = x; zy = y;
+            const T d_origin = Real<T>::sqrt(zx * zx + zy * zy);
+            const T d_axes = Real<T>::fmin(Real<T>::fabs(zx), Real<T>::fabs(zy));
+            const T dx = zx - cx, dy = zy - cy;
+            const T d_c = Real<T>::sqrt(dx * dx + dy * dy);
+            min_trap = Real<T>::fmin(min_trap, Real<T>::fmin(d_origin, Real<T>::fmin(d_axes, d_c)));
+            if (zx * zx + zy * zy > B2) { esc_i = i; live = false; }
+        }
+        done |= __builtin_amdgcn_ballot_w64(!live);
+    }
+    esc_zx = zx; esc_zy = zy;
+}
+
+/* ---- the kernel ------------------------------------------------------------------------------
+ * FRACTAL: 0 Mandelbrot, 1 Julia.  FPW_LOG2: log2 of the sub-tile width (3: 8x8, 4: 16x4, 6: 64x1).
+ * EFFECTS: trap / stripe / interior-style-2 variant (Mandelbrot only). */
+template <typename T, int FRACTAL, int FPW_LOG2, bool EFFECTS>
+__global__ void __launch_bounds__(kBlockThreads)
+escape_kernel(const LaunchArgs A)
+{
+    constexpr int FPW = 1 << FPW_LOG2;
+    constexpr int FPH = kWave / FPW;
+
+    __shared__ LdsBlock S;
+    if (threadIdx.x == 0) {
+        S.pal = A.pal;
+        S.center_x = A.center_x; S.center_y = A.center_y; S.zoom = A.zoom;
+        S.julia_cx = A.julia_cx; S.julia_cy = A.julia_cy; S.log_bailout = A.log_bailout;
+        S.bailout = A.bailout; S.color_offset = A.color_offset; S.color_scale = A.color_scale;
+        S.trap_radius = A.trap_radius; S.stripe_density = A.stripe_density;
+        S.brightness = A.brightness; S.saturation = A.saturation; S.contrast = A.contrast;
+        S.max_iter = A.max_iter; S.W = A.W; S.H = A.H; S.aa = A.aa;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int lx = lane & (FPW - 1);
+    const int ly = lane >> FPW_LOG2;
+
+    /* viewport constants out of LDS (broadcast reads), narrowed as the reference narrows
+     * them for its fp32 shaders (src/compute_effect_manager.h:85-90) */
+    const int W = S.W, H = S.H, max_iter = S.max_iter;
+    const int aa = S.aa > 1 ? S.aa : 1;
+    const T center_x = (T)S.center_x, center_y = (T)S.center_y, zoom = (T)S.zoom;
+    const T bailout = (T)S.bailout;
+    const T B2 = bailout * bailout;
+    const T resx = (T)W, resy = (T)H;
+
+    /* ---- persistent loop over the sharded tile queue ---- */
+    uint32_t shard = xcc_id();
+    uint32_t tried = 0;              /* shards found dry so far */
+    uint32_t seen = 0;               /* last head value observed on `shard` */
+
+    auto run_len = [&](uint32_t sh, uint32_t seen_head) -> uint32_t {
+        const uint32_t len = A.shard_len[sh];
+        const uint32_t rem = seen_head < len ? len - seen_head : 0u;
+        uint32_t n = rem >> A.run_shift;
+        n = n < 1u ? 1u : n;
+        return n > A.run_max ? A.run_max : n;
+    };
+    auto claim = [&](uint32_t sh, uint32_t n) -> uint32_t {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&A.queue[sh * kShardStrideWords], n);
+        return v;
+    };
+
+    uint32_t cur_n = run_len(shard, seen);
+    uint32_t cur_raw = claim(shard, cur_n);
+
+    for (;;) {
+        uint32_t begin = __builtin_amdgcn_readfirstlane(cur_raw);
+        uint32_t count = cur_n;
+        const uint32_t cur_shard = shard;
+        const uint32_t len = A.shard_len[cur_shard];
+        if (begin >= len) {
+            /* home shard dry: steal from the next one; exit after all 8 are dry */
+            if (++tried >= (uint32_t)kShards) break;
+            shard = (shard + 1u) & (uint32_t)(kShards - 1);
+            seen = 0;
+            cur_n = run_len(shard, seen);
+            cur_raw = claim(shard, cur_n);
+            continue;
+        }
+        if (begin + count > len) count = len - begin;
+        seen = begin + count;
+        /* issue the next dequeue now; it is consumed after this run's arithmetic */
+        const uint32_t next_n = run_len(shard, seen);
+        const uint32_t next_raw = claim(shard, next_n);
+
+        for (uint32_t j = begin; j < begin + count; ++j) {
+            /* shard-local index -> global sub-tile id (blocks of kShardBlock dealt round-robin) */
+            const uint32_t sid = ((j / kShardBlock) * kShards + cur_shard) * kShardBlock + (j % kShardBlock);
+            if (sid >= A.n_sub) continue;
+            const uint32_t sty = sid / A.nsx, stx = sid - sty * A.nsx;
+            const int px = (int)stx * FPW + lx;
+            const int lrow = (int)sty * FPH + ly;               /* row inside this part's packed rows */
+            const bool inside = px < W && lrow < A.rows_local;
+            /* packed local row -> frame row (row strips dealt round-robin to parts) */
+            const int strip = lrow / A.rows_per_strip;
+            const int py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
+            const uint64_t outside_mask = __builtin_amdgcn_ballot_w64(!inside);
+
+            float acc[3] = {0.0f, 0.0f, 0.0f};
+            T first_nu = T(0);
+            int first_it = 0;
+
+            const int nsamp = aa * aa;
+            for (int s = 0; s < nsamp; ++s) {
+                int it;
+                T nu;
+                float rgb[3];
+                if constexpr (FRACTAL == 0) {
+                    /* shaders/mandelbrot.comp:222-226 sample offsets, :149-151 viewport map */
+                    const int sy = s / aa, sx = s - sy * aa;
+                    const T pxs = (T)px + (T)sx / (T)aa;
+                    const T pys = (T)py + (T)sy / (T)aa;
+                    const T uvx = (pxs - T(0.5) * resx) / resy;
+                    const T uvy = (pys - T(0.5) * resy) / resy;
+                    const T cx = center_x + uvx * zoom;
+                    const T cy = center_y + uvy * zoom;
+                    if constexpr (!EFFECTS) {
+                        Orbit<T> o;
+                        o.X = T(0); o.Yd = T(0); o.x2 = T(0); o.y2d = T(0);
+                        o.cx = inside ? cx : T(0);
+                        o.cyd = inside ? T(2) * cy : T(0);
+                        /* |c| <= bailout for every live lane, else the first (tested) block
+                         * retires the lane at i = 0 anyway; fast_ok also needs B^2 >= 4.5 */
+                        T r2;
+                        escape_run<T>(o, B2, max_iter, A.fast_ok != 0, outside_mask, it, r2);
+                        nu = (T)it;                                           /* :172 */
+                        if (it < max_iter) {                                  /* :173-177 */
+                            const T log_zn = Real<T>::log(r2) / T(2);
+                            const T mu = Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
+                            nu = (T)it + T(1) - mu;
+                        }
+                        T t = nu / (T)max_iter * (T)S.color_scale;            /* :179 */
+                        t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
+                        if (it >= max_iter && A.interior_style == 1) {        /* :182-183 */
+                            rgb[0] = rgb[1] = rgb[2] = 0.0f;
+                        } else {                                              /* :190 */
+                            T u = t + (T)S.color_offset;
+                            u = u - Real<T>::floor(u);
+                            palette_eval(S.pal, (float)u, rgb);
+                        }
+                    } else {
+                        T zx = T(0), zy = T(0), ezx, ezy, min_trap;
+                        escape_run_effects<T>(zx, zy, inside ? cx : T(0), inside ? cy : T(0), B2,
+                                              max_iter, outside_mask, it, ezx, ezy, min_trap);
+                        nu = (T)it;
+                        if (it < max_iter) {
+                            const T log_zn = Real<T>::log(ezx * ezx + ezy * ezy) / T(2);
+                            const T mu = Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
+                            nu = (T)it + T(1) - mu;
+                        }
+                        T t = nu / (T)max_iter * (T)S.color_scale;
+                        t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
+                        bool coloured = false;
+                        if (it >= max_iter) {                                 /* :182-188 */
+                            if (A.interior_style == 1) { rgb[0] = rgb[1] = rgb[2] = 0.0f; coloured = true; }
+                            else if (A.interior_style == 2) {
+                                const float tf = expf(-(float)min_trap * 6.0f / fmaxf(S.trap_radius, 1e-6f));
+                                float u = S.color_offset + tf * 0.3f;
+                                u = u - floorf(u);
+                                palette_eval(S.pal, u, rgb);
+                                coloured = true;
+                            }
+                        }
+                        if (!coloured) {
+                            T u = t + (T)S.color_offset;
+                            u = u - Real<T>::floor(u);
+                            palette_eval(S.pal, (float)u, rgb);
+                            if (A.trap_enabled) {                             /* :193-198 */
+                                const float r = fmaxf(S.trap_radius, 1e-6f);
+                                const float tf = expf(-(float)min_trap * 4.0f / r);
+                                const float k = clamp01(tf * 0.8f);
+                                rgb[0] = rgb[0] * (1.0f - k) + 1.0f * k;
+                                rgb[1] = rgb[1] * (1.0f - k) + 0.8f * k;
+                                rgb[2] = rgb[2] * (1.0f - k) + 0.4f * k;
+                            }
+                            if (A.stripe_enabled) {                           /* :201-205 */
+                                const T angle = Real<T>::atan2(ezy, ezx);
+                                const float sv = 0.5f + 0.5f * (float)Real<T>::sin(angle * (T)S.stripe_density + nu * T(0.3));
+                                const float m = 0.7f * (1.0f - sv) + 1.3f * sv;
+                                rgb[0] *= m; rgb[1] *= m; rgb[2] *= m;
+                            }
+                        }
+                    }
+                } else {
+                    /* shaders/julia.comp:325 uv, :221-225 z0, :253-259 sample offsets (sx outer) */
+                    T uvx = (T)px / resx, uvy = (T)py / resy;
+                    if (aa > 1) {
+                        const int sx = s / aa, sy = s - sx * aa;
+                        const T pixel_size = T(1) / resx;
+                        const T sample_offset = pixel_size / (T)aa;
+                        const T centre = sample_offset * (T)(aa - 1) * T(0.5);
+                        uvx = uvx + ((T)sx * sample_offset - centre) / resx;
+                        uvy = uvy + ((T)sy * sample_offset - centre) / resy;
+                    }
+                    const T aspect = resx / resy;
+                    const T z0x = center_x + (uvx - T(0.5)) * zoom * aspect;
+                    const T z0y = center_y + (uvy - T(0.5)) * zoom;
+                    Orbit<T> o;
+                    o.X = inside ? z0x : T(0);
+                    o.Yd = inside ? T(2) * z0y : T(0);
+                    o.cx = inside ? (T)S.julia_cx : T(0);
+                    o.cyd = inside ? T(2) * (T)S.julia_cy : T(0);
+                    o.x2 = o.X * o.X;
+                    o.y2d = o.Yd * o.Yd;
+                    T r2;
+                    escape_run<T>(o, B2, max_iter, A.fast_ok != 0, outside_mask, it, r2);
+                    if (it < max_iter) {                                      /* :237-248 */
+                        nu = (T)it + T(1) - Real<T>::log(Real<T>::log(r2) / (T)S.log_bailout) / Real<T>::ln2();
+                        T t = nu / (T)max_iter;
+                        t = (T)S.color_offset + t * (T)S.color_scale;
+                        t = t - Real<T>::floor(t);
+                        palette_eval(S.pal, (float)t, rgb);
+                    } else {                                                  /* :243-244 */
+                        nu = (T)max_iter;
+                        rgb[0] = rgb[1] = rgb[2] = 0.0f;
+                    }
+                }
+                if (s == 0) { first_nu = nu; first_it = it; }
+                acc[0] += rgb[0]; acc[1] += rgb[1]; acc[2] += rgb[2];
+            }
+
+            if (aa > 1) {
+                const float n = (float)(aa * aa);
+                acc[0] /= n; acc[1] /= n; acc[2] /= n;
+            }
+            if (A.flags & FR_FLAG_POST_CHAIN)
+                post_chain(acc, S.brightness, S.saturation, S.contrast, FRACTAL == 1);
+
+            if (inside) {
+                const size_t o = (size_t)lrow * (size_t)W + (size_t)px;
+                if (A.rgba) A.rgba[o] = make_float4(acc[0], acc[1], acc[2], 1.0f);
+                if (A.nu) reinterpret_cast<T*>(A.nu)[o] = first_nu;
+                if (A.iter) A.iter[o] = first_it;
+            }
+        }
+
+        cur_raw = next_raw;
+        cur_n = next_n;
+    }
+}
+
+/* ---- 8-bit export: src/vk_engine.cpp:1344-1371 on the GPU ------------------------------------ */
+__global__ void __launch_bounds__(kBlockThreads)
+export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8,
+                   int W, int H, int through_half)
+{
+    const size_t n = (size_t)W * (size_t)H;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / (size_t)W), x = (int)(idx - (size_t)y * W);
+        const int flipped = H - 1 - y;                                        /* :1359 */
+        const float4 v = rgba[(size_t)flipped * W + x];
+        float c[3] = {v.x, v.y, v.z};
+        uint8_t q[3];
+        for (int k = 0; k < 3; ++k) {
+            float f = c[k];
+            if (through_half) f = __half2float(__float2half_rn(f));
+            f = aces(f);                                                      /* :1366 */
+            f = powf(f, 1.0f / 2.2f);                                         /* :1367 */
+            q[k] = (uint8_t)(f * 255.0f);                                     /* :1368 */
+        }
+        rgb8[idx * 3 + 0] = q[0]; rgb8[idx * 3 + 1] = q[1]; rgb8[idx * 3 + 2] = q[2];
+    }
+}
+
+}  // namespace fr

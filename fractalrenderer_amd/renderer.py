@@ -1,0 +1,172 @@
+"""Renderer: the Python face of the C-ABI render entry points.
+
+Mirrors the reference's compute boundary for the hot path:
+  ComputeEffectManager::dispatch(cmd, type, state, time, desc_set, extent)
+      src/compute_effect_manager.h:435-468
+  AnimationRenderer::RenderFrameCallback  bool(const FractalState&, width, height, path)
+      src/animation_renderer.h:41-48
+PyTorch is used only for device memory and streams; every pixel is computed by the HIP
+kernels behind libfractalrenderer_amd.so.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+from .state import FractalState, FractalType, Precision
+
+
+@dataclass(frozen=True)
+class Shard:
+    """Row-strip sharding of one frame (fr_shard): strips of rows_per_strip rows dealt
+    round-robin to nparts parts; this part renders only its own strips, packed."""
+    part: int = 0
+    nparts: int = 1
+    rows_per_strip: int = 0
+
+    def to_c(self) -> _capi.fr_shard:
+        return _capi.fr_shard(self.part, self.nparts, self.rows_per_strip)
+
+    def rows(self, height: int) -> int:
+        s = self.to_c()
+        return int(_capi.lib().fr_shard_rows(C.byref(s), height))
+
+    def global_rows(self, height: int) -> np.ndarray:
+        """frame row index of every packed local row of this part"""
+        s = self.to_c()
+        n = self.rows(height)
+        L = _capi.lib()
+        return np.array([L.fr_shard_global_row(C.byref(s), height, r) for r in range(n)], dtype=np.int64)
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class Renderer:
+    """One fr_ctx bound to one HIP device."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _capi.lib()
+        h = C.c_void_p()
+        _capi.check(self._lib.fr_ctx_create(int(device), C.byref(h)))
+        self._ctx = h
+        self.device = int(device)
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None):
+            self._lib.fr_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def compute_units(self) -> int:
+        return _capi.check(self._lib.fr_ctx_compute_units(self._ctx))
+
+    def set_tuning(self, workgroups_per_cu: int = 0, subtiles_per_dequeue: int = 0, shape: int = 0) -> None:
+        """shape: 0 automatic, 3: 8x8 sub-tiles, 4: 16x4, 6: 64x1"""
+        _capi.check(self._lib.fr_ctx_set_tuning(self._ctx, workgroups_per_cu,
+                                                (shape << 24) | (subtiles_per_dequeue & 0xFFFFFF)))
+
+    def last_kernel_ms(self) -> float:
+        return float(self._lib.fr_ctx_last_kernel_ms(self._ctx))
+
+    # -- plane plumbing ------------------------------------------------------------------
+    @staticmethod
+    def _ptr(x, want_dtype: str, nelem: int, what: str):
+        if x is None:
+            return None, None
+        if _is_torch(x):
+            if not x.is_contiguous():
+                raise ValueError(f"{what}: tensor must be contiguous")
+            if str(x.dtype).replace("torch.", "") != want_dtype:
+                raise ValueError(f"{what}: dtype {x.dtype}, expected {want_dtype}")
+            if x.numel() != nelem:
+                raise ValueError(f"{what}: {x.numel()} elements, expected {nelem}")
+            return x.data_ptr(), ("device" if x.is_cuda else "host")
+        a = x
+        if not isinstance(a, np.ndarray) or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"{what}: need a C-contiguous numpy array or torch tensor")
+        if a.dtype != np.dtype(want_dtype):
+            raise ValueError(f"{what}: dtype {a.dtype}, expected {want_dtype}")
+        if a.size != nelem:
+            raise ValueError(f"{what}: {a.size} elements, expected {nelem}")
+        return a.ctypes.data, "host"
+
+    def _output(self, precision: Precision, rows: int, width: int, rgba, nu, it) -> _capi.fr_output:
+        npx = rows * width
+        nu_dtype = "float64" if precision == Precision.F64 else "float32"
+        kinds = set()
+        o = _capi.fr_output()
+        for name, x, dt, n in (("rgba", rgba, "float32", npx * 4), ("nu", nu, nu_dtype, npx), ("iter", it, "int32", npx)):
+            p, kind = self._ptr(x, dt, n, name)
+            setattr(o, name, p)
+            if kind:
+                kinds.add(kind)
+        if len(kinds) > 1:
+            raise ValueError("output planes must all be host or all be device memory")
+        o.memory = _capi.FR_MEM_DEVICE if kinds == {"device"} else _capi.FR_MEM_HOST
+        return o
+
+    # -- render ----------------------------------------------------------------------------
+    def render(self, state: FractalState, width: int, height: int, *,
+               fractal_type: FractalType = FractalType.Mandelbrot,
+               precision: Precision = Precision.F64, post_chain: bool = False,
+               rgba=None, nu=None, iter=None, shard: Optional[Shard] = None,
+               stream: Optional[int] = None, sync: bool = True) -> None:
+        """The reference's render(viewport, max_iter, out_buffer) surface.
+
+        rgba: rows*W*4 float32, nu: rows*W float64 (F64) / float32 (F32), iter: rows*W int32;
+        numpy arrays (host, PCIe-inclusive path) or torch CUDA tensors (device, no copies).
+        sync=False enqueues on `stream` (a raw hipStream_t handle, e.g.
+        torch.cuda.current_stream().cuda_stream) and returns at once (device planes only).
+        """
+        p = state.to_params(fractal_type, precision, post_chain)
+        rows = shard.rows(height) if shard else height
+        out = self._output(precision, rows, width, rgba, nu, iter)
+        sh = shard.to_c() if shard else None
+        shp = C.byref(sh) if sh is not None else None
+        if sync:
+            if stream is not None:
+                raise ValueError("stream is only meaningful with sync=False")
+            _capi.check(self._lib.fr_render_shard(self._ctx, C.byref(p), width, height, shp, C.byref(out)))
+        else:
+            _capi.check(self._lib.fr_render_shard_async(self._ctx, C.byref(p), width, height, shp,
+                                                        C.byref(out), C.c_void_p(stream or 0)))
+
+    def dispatch(self, fractal_type: FractalType, state: FractalState, extent: tuple, **kw) -> None:
+        """Name-for-name mirror of ComputeEffectManager::dispatch (type, state, extent);
+        the Vulkan command buffer / descriptor set arguments become the output planes."""
+        self.render(state, int(extent[0]), int(extent[1]), fractal_type=fractal_type, **kw)
+
+    def export_rgb8(self, rgba, width: int, height: int, out=None, through_half: bool = False):
+        """8-bit export of VulkanEngine::render_animation_frame (src/vk_engine.cpp:1344-1371):
+        second ACES + gamma, u8 truncation, vertical flip."""
+        p_in, kind_in = self._ptr(rgba, "float32", width * height * 4, "rgba")
+        if out is None:
+            if kind_in == "device":
+                import torch
+                out = torch.empty((height, width, 3), dtype=torch.uint8, device=rgba.device)
+            else:
+                out = np.empty((height, width, 3), np.uint8)
+        p_out, kind_out = self._ptr(out, "uint8", width * height * 3, "rgb8")
+        if kind_in != kind_out:
+            raise ValueError("rgba and rgb8 must live in the same memory kind")
+        mem = _capi.FR_MEM_DEVICE if kind_in == "device" else _capi.FR_MEM_HOST
+        _capi.check(self._lib.fr_export_rgb8(self._ctx, p_in, width, height, p_out, mem, int(through_half)))
+        return out

@@ -1,0 +1,292 @@
+/*
+ * fractalrenderer_amd.h -- C ABI of the MI355X-native escape-time renderer.
+ *
+ * This is the drop-in boundary for the ONE hot path of franklynch/FractalRenderer:
+ * the per-pixel z <- z^2 + c iteration with smooth colouring (Mandelbrot/Julia).
+ * Every entry point below replaces the reference interface cited next to it.
+ * Path shorthand: src/ = FractalRenderer/src/, shaders/ = FractalRenderer/shaders/.
+ *
+ * Conventions
+ *   - plain C11, no C++ or torch types; all pointers + sizes.
+ *   - every function returns an fr_status (0 = FR_OK, < 0 = error) unless noted;
+ *     nothing aborts (the reference's VK_CHECK aborts, src/vk/vk_types.h:143-150).
+ *     fr_last_error() returns a thread-local message for the last failure.
+ *   - there is NO CPU fallback: a render call without a usable HIP device fails
+ *     with FR_ERR_NO_DEVICE.
+ *   - image layout: row-major, row 0 = smallest pixel y (as gl_GlobalInvocationID.y,
+ *     shaders/mandelbrot.comp:215; no vertical flip), RGBA f32, alpha = 1.
+ */
+#ifndef FRACTALRENDERER_AMD_H
+#define FRACTALRENDERER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_VERSION_MAJOR 0
+#define FR_VERSION_MINOR 1
+
+typedef enum fr_status {
+    FR_OK               =  0,
+    FR_ERR_INVALID_ARG  = -1,   /* NULL pointer, w/h == 0, max_iter outside [1, 2^24], zoom 0/non-finite ... */
+    FR_ERR_NO_DEVICE    = -2,   /* no HIP device / device ordinal out of range */
+    FR_ERR_HIP          = -3,   /* a HIP runtime call failed (message has the hipError string) */
+    FR_ERR_UNSUPPORTED  = -4,   /* fractal type outside the hot path (only Mandelbrot, JuliaSet) */
+    FR_ERR_IO           = -5,   /* .franim file could not be read / written */
+    FR_ERR_PARSE        = -6,   /* .franim JSON malformed or a required key is missing */
+    FR_ERR_NOMEM        = -7
+} fr_status;
+
+/* FractalType, src/fractal_state.h:6-14 (same numeric values). Only the first two
+ * are on the hot path; the others return FR_ERR_UNSUPPORTED. */
+typedef enum fr_fractal_type {
+    FR_FRACTAL_MANDELBROT   = 0,
+    FR_FRACTAL_JULIA        = 1,
+    FR_FRACTAL_BURNING_SHIP = 2,
+    FR_FRACTAL_MANDELBULB   = 3,
+    FR_FRACTAL_PHOENIX      = 4,
+    FR_FRACTAL_DEEP_ZOOM    = 5
+} fr_fractal_type;
+
+/* Arithmetic type of the iteration.  The reference computes in fp32 only
+ * (shaders/mandelbrot.comp:147-170) after narrowing its double viewport
+ * (src/compute_effect_manager.h:85-90); FR_PRECISION_F64 keeps the doubles. */
+typedef enum fr_precision {
+    FR_PRECISION_F32 = 0,
+    FR_PRECISION_F64 = 1
+} fr_precision;
+
+/* fr_params.flags */
+#define FR_FLAG_POST_CHAIN   0x1u  /* apply enhance_color -> aces_tonemap -> pow(1/2.2)
+                                      (shaders/mandelbrot.comp:233-235, shaders/julia.comp:330-337);
+                                      default is the LINEAR colour, before that chain */
+
+/*
+ * fr_params -- the hot-path fields of FractalState (src/fractal_state.h:16-91),
+ * i.e. the union of what ComputeEffect::update_from_state packs for Mandelbrot
+ * (src/compute_effect_manager.h:84-113) and Julia (:115-140).  centre/zoom stay
+ * double: the fp64 kernels need what the reference throws away at :86-88.
+ * fr_params_default() fills the FractalState member initialisers.
+ */
+typedef struct fr_params {
+    int32_t fractal_type;          /* fr_fractal_type                                   */
+    int32_t precision;             /* fr_precision                                      */
+    double  center_x;              /* src/fractal_state.h:18   default -0.5             */
+    double  center_y;              /*                   :19    default  0.0             */
+    double  zoom;                  /*                   :20    default  3.0  (view height in c-plane units) */
+    int32_t max_iterations;        /*                   :21    default  256             */
+    float   bailout;               /*                   :36    default  4.0; test is |z|^2 > bailout^2 */
+    double  julia_c_real;          /*                   :29    default -0.7f  (float in the reference)  */
+    double  julia_c_imag;          /*                   :30    default  0.27015f        */
+    int32_t antialiasing_samples;  /*                   :37    default  1  (n -> n x n samples)         */
+    int32_t palette_mode;          /*                   :40    default  0               */
+    float   color_offset;          /*                   :41    default  0               */
+    float   color_scale;           /*                   :42    default  1               */
+    int32_t interior_style;        /*                   :47    default  0               */
+    int32_t orbit_trap_enabled;    /*                   :48    default  0 (bool)        */
+    float   orbit_trap_radius;     /*                   :49    default  0.5             */
+    int32_t stripe_enabled;        /*                   :50    default  0 (bool)        */
+    float   stripe_density;        /*                   :51    default  10              */
+    float   color_brightness;      /*                   :77    default  1               */
+    float   color_saturation;      /*                   :78    default  1               */
+    float   color_contrast;        /*                   :79    default  1               */
+    uint32_t flags;                /* FR_FLAG_*                                         */
+} fr_params;
+
+/* ---- parameters ------------------------------------------------------------------ */
+
+/* FractalState{} member initialisers, src/fractal_state.h:18-51,77-79;
+ * fractal_type = Mandelbrot, precision = FR_PRECISION_F64, flags = 0. */
+int fr_params_default(fr_params* p);
+
+/* FractalState::reset(), src/fractal_state.h:135-153: centre (-0.5,0), zoom 1.5 (NOT 3.0),
+ * max_iterations 256, brightness/saturation/contrast 1; other fields untouched. */
+int fr_params_reset(fr_params* p);
+
+/* Validation the reference does not do (it patches or aborts, src/compute_effect_manager.h:335-345).
+ * width,height > 0; width*height < 2^31; max_iterations in [1, 2^24] (ints travel as floats
+ * through the push constants, exact to 2^24, shaders/mandelbrot.comp:18); zoom finite and != 0;
+ * centre finite; bailout finite > 0; antialiasing_samples in [0, 16]; fractal/precision known. */
+int fr_params_validate(const fr_params* p, uint32_t width, uint32_t height);
+
+/* ComputeEffect::update_from_state, src/compute_effect_manager.h:84-113 (Mandelbrot) and
+ * :115-140 (Julia): the 80-byte ComputePushConstants block (:11-17) as 20 floats,
+ * bit-for-bit (every field static_cast<float>). */
+int fr_pack_push_constants(const fr_params* p, float out[20]);
+
+/* ---- context ---------------------------------------------------------------------- */
+
+typedef struct fr_ctx fr_ctx;   /* owns the device ordinal, a stream, timing events and the
+                                   tile-queue words; not re-entrant, distinct contexts may
+                                   run concurrently (reference: single thread, src/vk_engine.cpp) */
+
+/* Replaces ComputeEffectManager's constructor + init_pipelines
+ * (src/compute_effect_manager.cpp:19-60,120-140): binds a HIP device; kernels are
+ * precompiled for gfx950 in this library, there is nothing to load at run time. */
+int  fr_ctx_create(int device_ordinal, fr_ctx** out);
+void fr_ctx_destroy(fr_ctx* ctx);
+
+/* ---- render ----------------------------------------------------------------------- */
+
+typedef enum fr_memory {
+    FR_MEM_DEVICE = 0,    /* pointers are HIP device pointers on ctx's device (no copies)   */
+    FR_MEM_HOST   = 1     /* pointers are host memory; the library stages through device
+                             scratch it owns and copies back (PCIe-inclusive path)          */
+} fr_memory;
+
+/* Output planes of one render.  rgba is required unless nu or iter is given. */
+typedef struct fr_output {
+    float*   rgba;     /* rows*W*4 f32, linear colour (or post-chained with FR_FLAG_POST_CHAIN) */
+    void*    nu;       /* rows*W smooth iteration count of sample (0,0): double for
+                          FR_PRECISION_F64, float for FR_PRECISION_F32; max_iterations
+                          for interior pixels.  NULL to skip                                */
+    int32_t* iter;     /* rows*W index i of the escaping update (shaders/mandelbrot.comp:157-170),
+                          max_iterations for interior.  NULL to skip                        */
+    int32_t  memory;   /* fr_memory                                                         */
+} fr_output;
+
+/* Row-strip sharding of one frame over the GPUs of a node: the frame's rows are cut
+ * into strips of rows_per_strip rows, dealt round-robin: strip s belongs to part
+ * (s % nparts).  Part `part` renders only its strips, packed densely in strip order,
+ * into its fr_output (fr_shard_rows() rows).  {0,1,0} = the whole frame. */
+typedef struct fr_shard {
+    uint32_t part;
+    uint32_t nparts;
+    uint32_t rows_per_strip;   /* 0 with nparts == 1 means "whole frame" */
+} fr_shard;
+
+/* number of rows part `part` owns / first-row table helpers (host-side arithmetic only) */
+uint32_t fr_shard_rows(const fr_shard* s, uint32_t height);
+/* global row index of local row `local_row` of this part; UINT32_MAX if out of range */
+uint32_t fr_shard_global_row(const fr_shard* s, uint32_t height, uint32_t local_row);
+
+/*
+ * fr_render -- the reference's render(viewport, max_iter, out_buffer) surface:
+ *   AnimationRenderer::RenderFrameCallback  bool(const FractalState&, uint32_t width,
+ *   uint32_t height, const std::string& path)  src/animation_renderer.h:41-48, whose body
+ *   VulkanEngine::render_animation_frame (src/vk_engine.cpp:1181-1418) reaches
+ *   ComputeEffectManager::dispatch (src/compute_effect_manager.h:435-468) ->
+ *   vkCmdDispatch(ceil(W/16), ceil(H/16), 1) of shaders/mandelbrot.comp / julia.comp.
+ * Synchronous: returns after the planes are complete (reference: immediate_submit waits
+ * on its fence, src/vk_engine.cpp:2319-2321).
+ */
+int fr_render(fr_ctx* ctx, const fr_params* p, uint32_t width, uint32_t height,
+              const fr_output* out);
+
+/* Same, restricted to one part of a row-strip sharding (multi-GPU row bands). */
+int fr_render_shard(fr_ctx* ctx, const fr_params* p, uint32_t width, uint32_t height,
+                    const fr_shard* shard, const fr_output* out);
+
+/* Asynchronous form for frame pipelining: enqueues on `hip_stream` (a hipStream_t passed
+ * as void*; NULL = the context's own stream) and returns without waiting.  Device memory
+ * only.  Launch-only: no allocation, no synchronisation (graph-capture safe). */
+int fr_render_shard_async(fr_ctx* ctx, const fr_params* p, uint32_t width, uint32_t height,
+                          const fr_shard* shard, const fr_output* out, void* hip_stream);
+
+/* Device time of the most recent render's kernel on this context, from a HIP event pair
+ * recorded around the launch on the launch stream (blocks until that kernel is done).
+ * < 0 if nothing was rendered yet. */
+float fr_ctx_last_kernel_ms(fr_ctx* ctx);
+
+/* Tuning knobs of the persistent tile queue (defaults are picked per launch from
+ * the frame size and max_iterations): workgroups per CU and sub-tiles per dequeue.
+ * 0 restores the automatic choice. */
+int fr_ctx_set_tuning(fr_ctx* ctx, uint32_t workgroups_per_cu, uint32_t subtiles_per_dequeue);
+
+/* Number of compute units of the context's device (hipDeviceProp_t.multiProcessorCount). */
+int fr_ctx_compute_units(fr_ctx* ctx);
+
+/* ---- 8-bit export (reference a9) ------------------------------------------------------ */
+
+/* The CPU loop of VulkanEngine::render_animation_frame, src/vk_engine.cpp:1344-1371, on the
+ * GPU: per channel ACES tonemap -> pow(1/2.2) -> (uint8)(v*255) with a vertical flip
+ * (:1359), RGBA f32 in -> packed RGB8 out (rows*W*3).  through_half != 0 first rounds each
+ * channel to fp16 as the reference's rgba16f storage image does (shaders/mandelbrot.comp:5). */
+int fr_export_rgb8(fr_ctx* ctx, const float* rgba, uint32_t width, uint32_t height,
+                   uint8_t* rgb8, int32_t memory, int32_t through_half);
+
+/* ---- .franim animations --------------------------------------------------------------- */
+
+typedef struct fr_anim fr_anim;
+
+/* InterpolationType, src/animation_system.h:8-14 */
+typedef enum fr_interp {
+    FR_INTERP_LINEAR = 0, FR_INTERP_EASE_IN_OUT = 1, FR_INTERP_EASE_IN = 2,
+    FR_INTERP_EASE_OUT = 3, FR_INTERP_EXPONENTIAL = 4
+} fr_interp;
+
+/* Animation metadata, src/animation_system.h:24-35 */
+typedef struct fr_anim_info {
+    float   duration;
+    int32_t loop;
+    int32_t target_fps;
+    int32_t export_width;
+    int32_t export_height;
+    int32_t keyframe_count;
+} fr_anim_info;
+
+/* One Keyframe (src/animation_system.h:16-22) restricted to the fields
+ * AnimationSystem::load_from_file reads (src/animation_system.cpp:291-301). */
+typedef struct fr_keyframe {
+    float   time;
+    int32_t interp_type;
+    fr_params state;
+} fr_keyframe;
+
+/* AnimationSystem::load_from_file, src/animation_system.cpp:275-313: parses the .franim
+ * JSON.  Required keys exactly as the reference reads them: top level name, description,
+ * duration, loop, target_fps, export_width, export_height, keyframes[]; per keyframe time,
+ * interp_type, center_x, center_y, zoom, max_iterations, palette_mode, color_offset,
+ * color_scale.  The extra keys the reference's writer emits (:246-255) are accepted and
+ * loaded when present.  Keyframes keep file order (the reference does not sort on load). */
+int  fr_anim_load(const char* path, fr_anim** out);
+int  fr_anim_parse(const char* json, size_t len, fr_anim** out);
+void fr_anim_free(fr_anim* a);
+
+/* AnimationSystem::save_to_file, src/animation_system.cpp:221-273 (same 19 keyframe keys). */
+int  fr_anim_save(const fr_anim* a, const char* path);
+
+int  fr_anim_get_info(const fr_anim* a, fr_anim_info* info);
+int  fr_anim_get_keyframe(const fr_anim* a, int32_t index, fr_keyframe* out);
+/* name / description strings (owned by the animation) */
+const char* fr_anim_name(const fr_anim* a);
+const char* fr_anim_description(const fr_anim* a);
+
+/* Empty animation (AnimationSystem ctor, src/animation_system.cpp:7-10: duration 10) and
+ * AnimationSystem::add_keyframe (:12-23: append, stable-sort by time, extend duration to
+ * time+1 when time > duration). */
+int  fr_anim_create(fr_anim** out);
+int  fr_anim_add_keyframe(fr_anim* a, float time, const fr_params* state, int32_t interp_type);
+
+/* AnimationSystem::interpolate(time), src/animation_system.cpp:82-181 (+ find_keyframe_pair
+ * :183-197, easing :199-212).  `base` is the live FractalState returned when there are no
+ * keyframes (:83); fields the reference leaves at FractalState defaults because `result` is
+ * default-constructed (:125) come out as fr_params_default() values.  fractal_type/precision/
+ * flags are not animated: they are copied from `base`. */
+int  fr_anim_state_at(const fr_anim* a, float time, const fr_params* base, fr_params* out);
+
+/* AnimationRenderer::start_render frame arithmetic, src/animation_renderer.cpp:48,80:
+ * total_frames = int(duration * target_fps); time(frame) = frame / float(target_fps). */
+int32_t fr_anim_frame_count(const fr_anim* a);
+float   fr_anim_frame_time(const fr_anim* a, int32_t frame);
+
+/* ---- deep-zoom reference orbit (reference a8) ------------------------------------------- */
+
+/* DeepZoomManager::compute_reference_orbit fp64 loop, src/deep_zoom_system.cpp:378-424:
+ * single point, host side in the reference too.  out_xy has room for max_iter (re,im)
+ * pairs; *out_len receives the trimmed length. */
+int fr_reference_orbit(double cx, double cy, int32_t max_iter, double* out_xy, int32_t* out_len);
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+
+const char* fr_last_error(void);
+const char* fr_status_string(int status);
+void        fr_version(int* major, int* minor);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRACTALRENDERER_AMD_H */

@@ -1,0 +1,76 @@
+"""world_size-2 (and 3) gloo tests of the N > 1 path on CPU: row-strip ownership, the gather to the
+root and the root's de-interleave.  The HIP renderer cannot run here, so each rank's strips are
+produced by the CPU oracle (test infrastructure standing in for the kernel); what is under test is
+fractalrenderer_amd/distributed.py + the C ABI's strip arithmetic."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, R, nframes, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fractalrenderer_amd.distributed import StripGather
+        from oracle import oracle as O
+        sg = StripGather(W, H, 4, torch.float32, torch.device("cpu"), rows_per_strip=R)
+
+        def render_fn(shard, out, frame):
+            p = O.OracleParams(max_iterations=64 + 32 * frame)
+            rows = shard.global_rows(H)
+            assert out.shape[0] == len(rows)
+            for k, y in enumerate(rows):
+                out[k] = torch.from_numpy(O.render(p, W, H, y0=int(y), y1=int(y) + 1, threads=1, planes=False).rgba[0])
+
+        ok = True
+        for f in range(nframes):
+            slot = sg.submit(render_fn, f)
+            sg.drain()
+            if rank == 0:
+                ref = O.render(O.OracleParams(max_iterations=64 + 32 * f), W, H, threads=1, planes=False).rgba
+                ok = ok and np.array_equal(sg.frames[slot].numpy(), ref)
+        one = sg.render_frame(render_fn, 0)
+        if rank == 0:
+            ref = O.render(O.OracleParams(max_iterations=64), W, H, threads=1, planes=False).rgba
+            ok = ok and np.array_equal(one.numpy(), ref)
+            q.put((ok, sg.R, sg.even))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,R", [(2, 40, 32, 4), (2, 24, 23, 5), (3, 16, 30, 0), (2, 8, 3, 2)])
+def test_strip_gather_gloo(oracle, fr, world, W, H, R):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, R, 3, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ok, used_R, even = q.get(timeout=5)
+    assert ok
+    if R == 0:
+        assert H % (world * used_R) == 0 and even       # automatic strip height divides the frame evenly
+
+
+def test_pick_rows_per_strip(fr):
+    from fractalrenderer_amd.distributed import pick_rows_per_strip
+    assert pick_rows_per_strip(4096, 8) == 32 and pick_rows_per_strip(8192, 8) == 32
+    assert pick_rows_per_strip(4096, 1) == 32 and pick_rows_per_strip(1440, 8) == 30
+    assert pick_rows_per_strip(7, 8) == 1 and pick_rows_per_strip(1000, 3) == 1

@@ -1,0 +1,303 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bars:
+  * escape index `iter`: bit-exact (integer) in fp64 AND fp32 -- both sides perform the same IEEE
+    operations in the same order, no contraction;
+  * smooth iteration count nu, fp64: |dnu| <= 1e-9 asserted (the north-star tolerance is 1e-6); the
+    only difference is the log() implementation (OCML vs glibc), a few ulp;
+  * nu, fp32: |dnu| <= 4 ulp32(nu) + 4e-6 (same reason, in float);
+  * colour: |d| <= 2e-5 per channel (powf/expf implementations), except pixels whose palette argument
+    sits within 1e-4 of the fract() wrap, where a 1-ulp nu difference legitimately flips the colour
+    (fp32 only; the fp64 planes never hit it).
+"""
+import numpy as np
+import pytest
+
+from cases import CASES, MANDEL_PALETTES, JULIA_PALETTES
+
+pytestmark = pytest.mark.gpu
+
+NU_TOL_F64 = 1e-9
+RGB_TOL = 2e-5
+
+
+def to_state(fr, p):
+    return fr.FractalState(center_x=p.center_x, center_y=p.center_y, zoom=p.zoom, max_iterations=p.max_iterations,
+                           julia_c_real=p.julia_c_real, julia_c_imag=p.julia_c_imag, bailout=p.bailout,
+                           antialiasing_samples=p.aa, palette_mode=p.palette_mode, color_offset=p.color_offset,
+                           color_scale=p.color_scale, interior_style=p.interior_style,
+                           orbit_trap_enabled=bool(p.orbit_trap_enabled), orbit_trap_radius=p.orbit_trap_radius,
+                           stripe_enabled=bool(p.stripe_enabled), stripe_density=p.stripe_density,
+                           color_brightness=p.brightness, color_saturation=p.saturation, color_contrast=p.contrast)
+
+
+def gpu_render(fr, renderer, p, W, H, shard=None, host=False):
+    import torch
+    prec = fr.Precision.F64 if p.precision == 1 else fr.Precision.F32
+    rows = shard.rows(H) if shard else H
+    if host:
+        rgba = np.full((rows, W, 4), -7.0, np.float32)
+        nu = np.full((rows, W), -7.0, np.float64 if p.precision == 1 else np.float32)
+        it = np.full((rows, W), -7, np.int32)
+    else:
+        dev = torch.device("cuda:0")
+        rgba = torch.full((rows, W, 4), -7.0, dtype=torch.float32, device=dev)
+        nu = torch.full((rows, W), -7.0, dtype=torch.float64 if p.precision == 1 else torch.float32, device=dev)
+        it = torch.full((rows, W), -7, dtype=torch.int32, device=dev)
+    renderer.render(to_state(fr, p), W, H, fractal_type=fr.FractalType(p.fractal), precision=prec,
+                    post_chain=bool(p.post_chain), rgba=rgba, nu=nu, iter=it, shard=shard)
+    if host:
+        return rgba, nu, it
+    return rgba.cpu().numpy(), nu.cpu().numpy(), it.cpu().numpy()
+
+
+def check_against(p, ref_iter, ref_nu, ref_rgba, rgba, nu, it):
+    assert np.array_equal(it, ref_iter), "escape indices differ: %d pixels" % int((it != ref_iter).sum())
+    nu = nu.astype(np.float64)
+    if p.precision == 1:
+        assert np.abs(nu - ref_nu).max() <= NU_TOL_F64
+    else:
+        ulp = np.spacing(np.maximum(np.abs(ref_nu), 1.0).astype(np.float32)).astype(np.float64)
+        assert np.all(np.abs(nu - ref_nu) <= 4 * ulp + 4e-6)
+    assert np.all(rgba[..., 3] == 1.0)
+    d = np.abs(rgba[..., :3] - ref_rgba[..., :3]).max(axis=-1)
+    bad = d > (RGB_TOL if not p.post_chain else 1e-4)
+    if bad.any():
+        assert p.precision == 0 and p.aa <= 1, "colour mismatch %g" % d.max()
+        # fp32: tolerate only pixels at the fract() wrap of the palette argument
+        scale, off, mi = np.float32(p.color_scale), np.float32(p.color_offset), np.float32(p.max_iterations)
+        nu32 = ref_nu.astype(np.float32)
+        t = (np.clip(nu32 / mi * scale, 0, 1) + off) if p.fractal == 0 else (off + nu32 / mi * scale)
+        u = t - np.floor(t)
+        near_wrap = np.minimum(u, 1 - u) < 1e-4
+        assert np.all(near_wrap[bad]), "colour mismatch %g away from the palette wrap" % d[bad & ~near_wrap].max()
+
+
+@pytest.mark.parametrize("shape", [3, 4, 6])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_case_matches_oracle_and_golden(fr, renderer, oracle, golden, name, shape):
+    p, W, H = CASES[name]
+    renderer.set_tuning(shape=shape)
+    try:
+        rgba, nu, it = gpu_render(fr, renderer, p, W, H)
+    finally:
+        renderer.set_tuning()
+    ref = oracle.render(p, W, H)
+    check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
+    g = golden["frames"]
+    check_against(p, g[name + "/iter"], g[name + "/nu"], g[name + "/rgba"], rgba, nu, it)
+
+
+@pytest.mark.parametrize("max_iter", [1, 2, 5, 15, 16, 17, 31, 32, 33, 100])
+def test_block_boundaries(fr, renderer, oracle, max_iter):
+    """max_iter around the 16-iteration block size of the unchecked fast path."""
+    for kw in (dict(), dict(fractal=1, center_x=0.0, julia_c_real=-0.8, julia_c_imag=0.156),
+               dict(precision=0), dict(center_x=-0.75, zoom=0.5)):
+        p = oracle.OracleParams(max_iterations=max_iter, **kw)
+        rgba, nu, it = gpu_render(fr, renderer, p, 72, 40)
+        ref = oracle.render(p, 72, 40)
+        check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
+
+
+def test_optional_planes_and_host_memory(fr, renderer, oracle):
+    import torch
+    p, W, H = CASES["c2_mandel_f64_mi1024_ragged"]
+    ref = oracle.render(p, W, H)
+    rgba, nu, it = gpu_render(fr, renderer, p, W, H, host=True)            # FR_MEM_HOST staging path
+    check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
+    st = to_state(fr, p)
+    only_nu = torch.empty((H, W), dtype=torch.float64, device="cuda:0")
+    renderer.render(st, W, H, nu=only_nu)                                   # a single plane is enough
+    assert np.abs(only_nu.cpu().numpy() - ref.nu).max() <= NU_TOL_F64
+    only_rgba = np.empty((H, W, 4), np.float32)
+    renderer.render(st, W, H, rgba=only_rgba)
+    assert np.abs(only_rgba - ref.rgba).max() <= RGB_TOL
+    assert renderer.last_kernel_ms() > 0.0
+
+
+def test_async_on_torch_stream(fr, renderer, oracle):
+    import torch
+    p, W, H = CASES["seahorse_0008_f64"]
+    s = torch.cuda.Stream()
+    nu = torch.zeros((H, W), dtype=torch.float64, device="cuda:0")
+    rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    with torch.cuda.stream(s):
+        renderer.render(to_state(fr, p), W, H, rgba=rgba, nu=nu, sync=False, stream=s.cuda_stream)
+        doubled = nu * 2            # ordered after the kernel on the same stream
+    s.synchronize()
+    ref = oracle.render(p, W, H)
+    assert np.abs(doubled.cpu().numpy() - 2 * ref.nu).max() <= 2 * NU_TOL_F64
+    with pytest.raises(fr.FractalRendererError):
+        renderer.render(to_state(fr, p), W, H, rgba=np.empty((H, W, 4), np.float32), sync=False, stream=s.cuda_stream)
+
+
+@pytest.mark.parametrize("nparts,R", [(2, 1), (2, 5), (3, 8), (8, 4), (8, 64), (5, 7)])
+def test_row_strip_shards_reassemble(fr, renderer, oracle, nparts, R):
+    p, W, H = CASES["c2_mandel_f64_mi1024_ragged"]
+    whole_rgba, whole_nu, whole_it = gpu_render(fr, renderer, p, W, H)
+    out_rgba = np.zeros_like(whole_rgba); out_nu = np.zeros_like(whole_nu); out_it = np.zeros_like(whole_it)
+    for part in range(nparts):
+        sh = fr.Shard(part, nparts, R)
+        rows = sh.global_rows(H)
+        rgba, nu, it = gpu_render(fr, renderer, p, W, H, shard=sh)
+        assert rgba.shape[0] == len(rows)
+        if len(rows):
+            out_rgba[rows], out_nu[rows], out_it[rows] = rgba, nu, it
+    assert np.array_equal(out_it, whole_it) and np.array_equal(out_nu, whole_nu) and np.array_equal(out_rgba, whole_rgba)
+    ref = oracle.render(p, W, H)
+    check_against(p, ref.iter, ref.nu, ref.rgba, out_rgba, out_nu, out_it)
+
+
+def test_all_palettes(fr, renderer, oracle):
+    for fractal, modes in ((0, MANDEL_PALETTES), (1, JULIA_PALETTES)):
+        for m in modes:
+            p = oracle.OracleParams(fractal=fractal, center_x=-0.5 if fractal == 0 else 0.0, palette_mode=m,
+                                    max_iterations=96, color_scale=2.5, color_offset=0.1)
+            rgba, nu, it = gpu_render(fr, renderer, p, 64, 40)
+            ref = oracle.render(p, 64, 40)
+            check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
+
+
+def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
+    """Work-queue geometry must never change a pixel: every (workgroups/CU, run length, sub-tile shape)
+    gives byte-identical planes."""
+    p, W, H = CASES["seahorse_0008_f64"]
+    base = gpu_render(fr, renderer, p, 200, 120)
+    try:
+        for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
+            renderer.set_tuning(wg, run, shape)
+            cur = gpu_render(fr, renderer, p, 200, 120)
+            for a, b in zip(base, cur):
+                assert np.array_equal(a, b)
+    finally:
+        renderer.set_tuning()
+
+
+def test_export_rgb8(fr, renderer, oracle):
+    p, W, H = CASES["c1_mandel_f64_default"]
+    rgba, _, _ = gpu_render(fr, renderer, p, W, H)
+    for through_half in (False, True):
+        got = renderer.export_rgb8(rgba, W, H, through_half=through_half)
+        ref = oracle.export_rgb8(rgba, through_half=through_half)
+        d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3       # powf may differ by an ulp at a truncation edge
+    import torch
+    dev = torch.from_numpy(rgba).cuda()
+    out = renderer.export_rgb8(dev, W, H)
+    assert out.is_cuda and np.array_equal(out.cpu().numpy(), renderer.export_rgb8(rgba, W, H))
+
+
+def test_render_errors(fr, renderer):
+    st = fr.FractalState()
+    buf = np.empty((8, 8, 4), np.float32)
+    with pytest.raises(fr.FractalRendererError) as e:
+        renderer.render(st, 8, 8, fractal_type=fr.FractalType.Phoenix, rgba=buf)
+    assert e.value.status == fr._capi.FR_ERR_UNSUPPORTED
+    with pytest.raises(fr.FractalRendererError):
+        renderer.render(fr.FractalState(max_iterations=0), 8, 8, rgba=buf)
+    with pytest.raises(fr.FractalRendererError):
+        renderer.render(st, 8, 8)                                  # no plane at all
+    with pytest.raises(ValueError):
+        renderer.render(st, 8, 8, rgba=np.empty((8, 8, 3), np.float32))
+    with pytest.raises(fr.FractalRendererError) as e:
+        fr.Renderer(99)
+    assert e.value.status == fr._capi.FR_ERR_NO_DEVICE
+
+
+# ---- BASELINE.json sizes: size-independent properties ---------------------------------------------------------------
+def test_c2_full_size_properties(fr, renderer, oracle):
+    """Mandelbrot 4096x4096, max_iter 1024, fp64 (the metric's configuration)."""
+    import torch
+    W = H = 4096
+    p = oracle.OracleParams(max_iterations=1024)
+    dev = torch.device("cuda:0")
+    rgba = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    nu = torch.empty((H, W), dtype=torch.float64, device=dev)
+    it = torch.empty((H, W), dtype=torch.int32, device=dev)
+    renderer.render(to_state(fr, p), W, H, rgba=rgba, nu=nu, iter=it)
+    # (1) conjugate symmetry: centre_y = 0, so rows y and H-y hold c and conj(c) exactly
+    assert torch.equal(it[1:], it[1:].flip(0)) and torch.equal(nu[1:], nu[1:].flip(0))
+    assert torch.equal(rgba[1:], rgba[1:].flip(0))
+    # (2) sampled rows against the oracle (full width, so every sub-tile column is covered)
+    for y0 in (0, 1000, 2040, 2048, 3333, 4088):
+        ref = oracle.render(p, W, H, y0=y0, y1=y0 + 8)
+        check_against(p, ref.iter, ref.nu, ref.rgba, rgba[y0:y0 + 8].cpu().numpy(), nu[y0:y0 + 8].cpu().numpy(),
+                      it[y0:y0 + 8].cpu().numpy())
+    # (3) interior fraction / mean iterations match the survey's workload table
+    it_h = it.cpu().numpy()
+    interior = float((it_h == 1024).mean())
+    mean_it = float(np.where(it_h < 1024, it_h.astype(np.int64) + 1, 1024).mean())
+    assert abs(interior - 0.168) < 0.003 and abs(mean_it - 177.9) < 1.0
+    # (4) checksum of checksums is independent of the queue geometry and of row-strip sharding
+    want = (int(it.to(torch.int64).sum()), float(nu.sum()), float(rgba.double().sum()))
+    try:
+        renderer.set_tuning(4, 3, 6)
+        nu2 = torch.empty_like(nu); it2 = torch.empty_like(it); rgba2 = torch.empty_like(rgba)
+        renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
+        assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba)
+    finally:
+        renderer.set_tuning()
+    tot_it, tot_nu = 0, 0.0
+    for part in range(8):
+        sh = fr.Shard(part, 8, 32)
+        n = sh.rows(H)
+        nus = torch.empty((n, W), dtype=torch.float64, device=dev); its = torch.empty((n, W), dtype=torch.int32, device=dev)
+        renderer.render(to_state(fr, p), W, H, nu=nus, iter=its, shard=sh)
+        rows = torch.from_numpy(sh.global_rows(H)).to(dev)
+        assert torch.equal(its, it[rows]) and torch.equal(nus, nu[rows])
+        tot_it += int(its.to(torch.int64).sum())
+    assert tot_it == want[0]
+
+
+def test_c3_julia_full_size_rows(fr, renderer, oracle):
+    """Julia c = -0.8+0.156i, 4096x4096, max_iter 2048, fp32."""
+    import torch
+    W = H = 4096
+    p = oracle.OracleParams(fractal=1, precision=0, center_x=0.0, center_y=0.0, zoom=3.0, max_iterations=2048,
+                            julia_c_real=-0.8, julia_c_imag=0.156)
+    dev = torch.device("cuda:0")
+    rgba = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    nu = torch.empty((H, W), dtype=torch.float32, device=dev)
+    it = torch.empty((H, W), dtype=torch.int32, device=dev)
+    renderer.render(to_state(fr, p), W, H, fractal_type=fr.FractalType.JuliaSet, precision=fr.Precision.F32,
+                    rgba=rgba, nu=nu, iter=it)
+    for y0 in (0, 1024, 2044, 2048, 4090):
+        y1 = min(H, y0 + 6)
+        ref = oracle.render(p, W, H, y0=y0, y1=y1)
+        check_against(p, ref.iter, ref.nu, ref.rgba, rgba[y0:y1].cpu().numpy(), nu[y0:y1].cpu().numpy(), it[y0:y1].cpu().numpy())
+    # point symmetry of a Julia set about the view centre: pixel (x,y) <-> (W-x, H-y) map to z0 and -z0
+    assert torch.equal(it[1:, 1:], it[1:, 1:].flip(0, 1))
+
+
+def test_c4_deep_zoom_window(fr, renderer, oracle):
+    """C4 view (Seahorse, zoom 1e-6, max_iter 16384, fp64) on a window the oracle finishes in seconds;
+    the 8192^2 frame's pixel pitch is kept by rendering a 8192-high frame's row band."""
+    p, W, H = CASES["c4_seahorse_deep_f64"]
+    p = type(p)(**{**p.__dict__})
+    W, H = 512, 8192
+    sh = fr.Shard(16, 64, 8)            # strips of 8 rows: this part = rows 128..135, 640..647, ... (128 rows)
+    rows = sh.global_rows(H)[:24]
+    rgba, nu, it = gpu_render(fr, renderer, p, W, H, shard=sh)
+    for r0 in (0, 8, 16):
+        y0 = int(rows[r0])
+        ref = oracle.render(p, W, H, y0=y0, y1=y0 + 8)
+        check_against(p, ref.iter, ref.nu, ref.rgba, rgba[r0:r0 + 8], nu[r0:r0 + 8], it[r0:r0 + 8])
+
+
+def test_c5_franim_frames(fr, renderer, oracle, golden):
+    """C5: frames of the reference's sample .franim (t = frame / target_fps), max_iter override 4096,
+    row strips dealt to 8 parts; one part of each sampled frame is checked against the oracle."""
+    a = fr.AnimationSystem()
+    assert a.load_from_file(golden["franim"])
+    W, H = 512, 512
+    for frame in (0, 300, 599, 1234, 2399):
+        st = a.interpolate(a.frame_time(frame))
+        st.max_iterations = 4096
+        sh = fr.Shard(frame % 8, 8, 16)
+        rows = sh.global_rows(H)
+        p = oracle.OracleParams(center_x=st.center_x, center_y=st.center_y, zoom=st.zoom, max_iterations=4096,
+                                palette_mode=st.palette_mode, color_offset=st.color_offset, color_scale=st.color_scale)
+        rgba, nu, it = gpu_render(fr, renderer, p, W, H, shard=sh)
+        y0 = int(rows[16])
+        ref = oracle.render(p, W, H, y0=y0, y1=y0 + 16)
+        check_against(p, ref.iter, ref.nu, ref.rgba, rgba[16:32], nu[16:32], it[16:32])

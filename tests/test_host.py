@@ -1,0 +1,356 @@
+"""Host-side logic behind the C ABI (no GPU, no compute calls): parameter block, push-constant
+packing, validation, row-strip arithmetic, .franim I/O, keyframe interpolation, frame timing,
+reference orbit, exported symbols, and the "no device -> loud failure" contract."""
+import ctypes as C
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f32 = np.float32
+
+
+# ---- C ABI surface -----------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(fr):
+    hdr = open(os.path.join(ROOT, "include", "fractalrenderer_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    L = C.CDLL(fr._capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    assert declared == set(fr._capi.SIGNATURES), declared ^ set(fr._capi.SIGNATURES)
+
+
+def test_struct_layout_matches_header(fr):
+    # fr_params: 2 i32, 3 f64, i32+f32, 2 f64, then 4-byte fields -> 112 bytes with natural alignment
+    assert C.sizeof(fr._capi.fr_params) == 112
+    assert fr._capi.fr_params.center_x.offset == 8 and fr._capi.fr_params.julia_c_real.offset == 40
+    assert C.sizeof(fr._capi.fr_output) == 32 and C.sizeof(fr._capi.fr_shard) == 12
+    major, minor = C.c_int(), C.c_int()
+    fr.lib().fr_version(C.byref(major), C.byref(minor))
+    assert (major.value, minor.value) == (0, 1)
+
+
+def test_no_device_fails_loudly(fr):
+    """The product path has no CPU fallback: without a GPU the context cannot be created."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(fr.FractalRendererError) as e:
+        fr.Renderer(0)
+    assert e.value.status == fr._capi.FR_ERR_NO_DEVICE and "no CPU path" in str(e.value)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "fractalrenderer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "oracle" not in text.lower(), f"{fn} mentions the oracle"
+
+
+# ---- defaults / reset (src/fractal_state.h) ---------------------------------------------------------------
+def test_params_default_and_reset(fr):
+    p = fr._capi.fr_params()
+    assert fr.lib().fr_params_default(C.byref(p)) == 0
+    assert (p.center_x, p.center_y, p.zoom, p.max_iterations) == (-0.5, 0.0, 3.0, 256)
+    assert p.bailout == 4.0 and p.antialiasing_samples == 1 and p.palette_mode == 0
+    assert p.julia_c_real == float(f32(-0.7)) and p.julia_c_imag == float(f32(0.27015))
+    assert (p.color_offset, p.color_scale, p.orbit_trap_radius, p.stripe_density) == (0.0, 1.0, 0.5, 10.0)
+    assert (p.color_brightness, p.color_saturation, p.color_contrast) == (1.0, 1.0, 1.0)
+    assert p.interior_style == 0 and p.orbit_trap_enabled == 0 and p.stripe_enabled == 0 and p.flags == 0
+    p.zoom, p.center_x, p.max_iterations, p.palette_mode = 0.01, 0.3, 999, 4
+    fr.lib().fr_params_reset(C.byref(p))
+    assert (p.center_x, p.center_y, p.zoom, p.max_iterations) == (-0.5, 0.0, 1.5, 256)    # reset() zoom is 1.5
+    assert p.palette_mode == 4                                                              # untouched by reset()
+    s = fr.FractalState()
+    q = s.to_params()
+    d = fr._capi.fr_params(); fr.lib().fr_params_default(C.byref(d))
+    assert bytes(q) == bytes(d)
+
+
+# ---- push constants (src/compute_effect_manager.h:84-140) -----------------------------------------------------
+def test_push_constants_mandelbrot(fr, oracle):
+    s = fr.FractalState(center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-6, max_iterations=16384,
+                        color_offset=0.25, color_scale=2.0, bailout=8.0, palette_mode=3, antialiasing_samples=2,
+                        interior_style=2, orbit_trap_enabled=True, orbit_trap_radius=0.75, stripe_density=12.5,
+                        stripe_enabled=True, color_brightness=1.1, color_saturation=0.9, color_contrast=1.2)
+    pc = fr.pack_push_constants(s, fr.FractalType.Mandelbrot)
+    expect = [f32(-0.743643887037151), f32(0.13182590420533), f32(1e-6), 16384.0,      # data1
+              0.25, 2.0, 8.0, 3.0,                                                      # data2
+              2.0, 2.0, 1.0, 0.75,                                                      # data3
+              12.5, 1.0, f32(1.1), f32(0.9),                                            # data4
+              f32(1.2), 0.0, 0.0, 0.0]                                                  # data5
+    assert pc.dtype == np.float32 and pc.tobytes() == np.array(expect, np.float32).tobytes()
+    # the double -> float narrowing is the reference's precision ceiling: centre loses its low bits
+    assert float(pc[0]) != s.center_x
+    op = oracle.OracleParams(center_x=s.center_x, center_y=s.center_y, zoom=s.zoom, max_iterations=16384,
+                             color_offset=0.25, color_scale=2.0, bailout=8.0, palette_mode=3, aa=2, interior_style=2,
+                             orbit_trap_enabled=1, orbit_trap_radius=0.75, stripe_density=12.5, stripe_enabled=1,
+                             brightness=1.1, saturation=0.9, contrast=1.2)
+    assert oracle.pack_push_constants(op).tobytes() == pc.tobytes()
+
+
+def test_push_constants_julia(fr, oracle):
+    s = fr.FractalState(center_x=0.0, zoom=3.0, max_iterations=2048, julia_c_real=-0.8, julia_c_imag=0.156,
+                        color_offset=0.1, color_scale=1.5, palette_mode=7, antialiasing_samples=4)
+    pc = fr.pack_push_constants(s, fr.FractalType.JuliaSet)
+    expect = [0.0, 0.0, 3.0, 2048.0, f32(-0.8), f32(0.156), 4.0, f32(0.1),
+              4.0, 1.5, 1.0, 1.0, 1.0, 7.0, 0.0, 0.0, 0, 0, 0, 0]
+    assert pc.tobytes() == np.array(expect, np.float32).tobytes()
+    op = oracle.OracleParams(fractal=1, center_x=0.0, max_iterations=2048, julia_c_real=-0.8, julia_c_imag=0.156,
+                             color_offset=0.1, color_scale=1.5, palette_mode=7, aa=4)
+    assert oracle.pack_push_constants(op).tobytes() == pc.tobytes()
+    with pytest.raises(fr.FractalRendererError) as e:
+        fr.pack_push_constants(s, fr.FractalType.Phoenix)
+    assert e.value.status == fr._capi.FR_ERR_UNSUPPORTED
+
+
+# ---- validation ---------------------------------------------------------------------------------------------
+def test_validation(fr):
+    L = fr.lib()
+
+    def st(w=64, h=64, **kw):
+        p = fr.FractalState().to_params()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return L.fr_params_validate(C.byref(p), w, h)
+
+    assert st() == 0
+    assert st(w=0) == fr._capi.FR_ERR_INVALID_ARG and st(h=0) == fr._capi.FR_ERR_INVALID_ARG
+    assert st(w=65536, h=32768) == fr._capi.FR_ERR_INVALID_ARG          # 2^31 pixels
+    assert st(w=32768, h=32768) == 0
+    assert st(max_iterations=0) == fr._capi.FR_ERR_INVALID_ARG
+    assert st(max_iterations=(1 << 24) + 1) == fr._capi.FR_ERR_INVALID_ARG and st(max_iterations=1 << 24) == 0
+    assert st(zoom=0.0) == fr._capi.FR_ERR_INVALID_ARG and st(zoom=math.inf) == fr._capi.FR_ERR_INVALID_ARG
+    assert st(zoom=-2.0) == 0                                            # a mirrored view is legal
+    assert st(center_x=math.nan) == fr._capi.FR_ERR_INVALID_ARG
+    assert st(bailout=0.0) == fr._capi.FR_ERR_INVALID_ARG and st(bailout=math.inf) == fr._capi.FR_ERR_INVALID_ARG
+    assert st(antialiasing_samples=17) == fr._capi.FR_ERR_INVALID_ARG and st(antialiasing_samples=0) == 0
+    assert st(precision=2) == fr._capi.FR_ERR_INVALID_ARG
+    for t in (fr.FractalType.BurningShip, fr.FractalType.Mandelbulb, fr.FractalType.Phoenix, fr.FractalType.Deep_Zoom):
+        assert st(fractal_type=int(t)) == fr._capi.FR_ERR_UNSUPPORTED
+    assert st(fractal_type=9) == fr._capi.FR_ERR_INVALID_ARG
+    assert b"outside the hot path" in L.fr_last_error() or b"unknown" in L.fr_last_error()
+    assert L.fr_status_string(-4) == b"fractal type outside the hot path"
+
+
+# ---- row strips ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,nparts,R", [(8192, 8, 64), (4096, 8, 32), (1000, 8, 64), (23, 3, 5), (7, 8, 1),
+                                        (5, 8, 64), (4096, 1, 0), (130, 4, 33), (1, 2, 1)])
+def test_shard_partition(fr, H, nparts, R):
+    owners = np.full(H, -1)
+    total = 0
+    for part in range(nparts):
+        sh = fr.Shard(part, nparts, R)
+        rows = sh.global_rows(H)
+        assert len(rows) == sh.rows(H)
+        assert np.all(np.diff(rows) > 0)                       # packed rows keep frame order
+        assert np.all(owners[rows] == -1)                      # disjoint
+        owners[rows] = part
+        total += len(rows)
+        RR = R if R else H
+        assert np.all((rows // RR) % nparts == part)           # strip s belongs to part s % nparts
+    assert total == H and np.all(owners >= 0)                  # exhaustive
+    s = fr.Shard(0, nparts, R).to_c()
+    assert fr.lib().fr_shard_global_row(C.byref(s), H, H + 5) == 0xFFFFFFFF
+
+
+# ---- .franim (src/animation_system.cpp:221-313) -----------------------------------------------------------------
+def py_interpolate(kfs, duration, time):
+    """Independent restatement of AnimationSystem::interpolate (src/animation_system.cpp:82-181)
+    in numpy scalar arithmetic (float32 where the reference uses float)."""
+    time = f32(min(max(f32(time), f32(0.0)), f32(duration)))
+    k1, k2 = len(kfs) - 2, len(kfs) - 1
+    for i in range(len(kfs) - 1):
+        if time >= f32(kfs[i]["time"]) and time <= f32(kfs[i + 1]["time"]):
+            k1, k2 = i, i + 1
+            break
+    a, b = kfs[k1], kfs[k2]
+    td = f32(b["time"]) - f32(a["time"])
+    if td < f32(0.001):
+        return dict(center_x=a["center_x"], center_y=a["center_y"], zoom=a["zoom"],
+                    max_iterations=a["max_iterations"], palette_mode=a["palette_mode"],
+                    color_offset=f32(a["color_offset"]), color_scale=f32(a["color_scale"]))
+    t = f32((time - f32(a["time"])) / td)
+    it = b["interp_type"]
+    if it == 1:
+        t = f32(2.0) * t * t if t < f32(0.5) else f32(1.0) - f32(np.power(f32(-2.0) * t + f32(2.0), f32(2.0))) / f32(2.0)
+    elif it in (2, 4):
+        t = t * t
+    elif it == 3:
+        t = f32(1.0) - (f32(1.0) - t) * (f32(1.0) - t)
+    t = f32(t)
+    td_ = float(t)                                        # float t widened for the double expressions
+    cx = a["center_x"] + td_ * (b["center_x"] - a["center_x"])
+    cy = a["center_y"] + td_ * (b["center_y"] - a["center_y"])
+    if a["zoom"] > 0 and b["zoom"] > 0:
+        zoom = math.exp(math.log(a["zoom"]) + td_ * (math.log(b["zoom"]) - math.log(a["zoom"])))
+    else:
+        zoom = a["zoom"] + td_ * (b["zoom"] - a["zoom"])
+    zoom = max(0.000001, zoom)
+    iter_t = f32(0.0) if t < f32(0.33) else (f32(0.5) if t < f32(0.67) else f32(1.0))
+    mi = int(f32(a["max_iterations"]) + iter_t * f32(b["max_iterations"] - a["max_iterations"]))
+    return dict(center_x=cx, center_y=cy, zoom=zoom, max_iterations=mi,
+                palette_mode=a["palette_mode"] if t < f32(0.5) else b["palette_mode"],
+                color_offset=f32(a["color_offset"]) + t * (f32(b["color_offset"]) - f32(a["color_offset"])),
+                color_scale=f32(a["color_scale"]) + t * (f32(b["color_scale"]) - f32(a["color_scale"])))
+
+
+def test_franim_load_reference_sample(fr, golden):
+    a = fr.AnimationSystem()
+    assert a.load_from_file(golden["franim"])
+    raw = json.load(open(golden["franim"]))
+    i = a.info
+    assert (i.duration, i.loop, i.target_fps, i.export_width, i.export_height) == (20.0, 1, 120, 2560, 1440)
+    assert i.keyframe_count == 6 and a.name == "" and a.description == ""
+    for kf, src in zip(a.get_keyframes(), raw["keyframes"]):
+        assert kf.time == src["time"] and int(kf.interp_type) == src["interp_type"]
+        for key in ("center_x", "center_y", "zoom", "max_iterations", "palette_mode", "color_offset", "color_scale"):
+            assert getattr(kf.state, key) == src[key], key
+        # fields the loader does not read stay at FractalState defaults (src/animation_system.cpp:290-298)
+        assert kf.state.bailout == 4.0 and kf.state.antialiasing_samples == 1 and kf.state.julia_c_real == float(f32(-0.7))
+    # frame arithmetic, src/animation_renderer.cpp:48,80
+    assert a.frame_count() == 2400 and a.frame_time(600) == 5.0 and a.frame_time(1) == float(f32(1) / f32(120))
+
+
+def test_franim_reference_recorded_keyframe(fr, golden):
+    """The sample's 6th keyframe (t = 20.0) is the reference's own interpolate(20.0) result saved
+    back as a keyframe: centre_y = 9.99999999995449e-06 and zoom = 0.0005000000000000001 are what
+    key3 -> key4 evaluate to at t = 1 in double arithmetic.  A known answer produced BY the reference."""
+    a = fr.AnimationSystem()
+    assert a.load_from_file(golden["franim"])
+    s = a.interpolate(20.0)
+    last = json.load(open(golden["franim"]))["keyframes"][5]
+    assert s.center_x == last["center_x"] == -1.7497
+    assert s.center_y == last["center_y"] == 9.99999999995449e-06
+    assert s.zoom == last["zoom"] == 0.0005000000000000001
+    assert s.max_iterations == last["max_iterations"] == 1024
+
+
+def test_franim_interpolate_matches_restatement(fr, golden):
+    a = fr.AnimationSystem()
+    assert a.load_from_file(golden["franim"])
+    raw = json.load(open(golden["franim"]))
+    times = [a.frame_time(f) for f in range(0, 2400, 37)] + [0.0, 4.999, 5.0, 5.001, 19.999, 20.0, 25.0, -1.0]
+    for t in times:
+        got = a.interpolate(t)
+        exp = py_interpolate(raw["keyframes"], raw["duration"], t)
+        for k, v in exp.items():
+            assert getattr(got, k) == (float(v) if isinstance(v, np.floating) else v), (t, k)
+        assert got.zoom >= 1e-6                                       # :145 floor
+
+
+def test_franim_interp_types_and_edge_cases(fr):
+    a = fr.AnimationSystem(fr.FractalState(zoom=7.0))
+    assert a.interpolate(1.0).zoom == 7.0                           # no keyframes -> live state (:83)
+    k0 = fr.FractalState(center_x=0.0, zoom=1.0, max_iterations=100, palette_mode=1, color_offset=0.0, bailout=8.0,
+                         antialiasing_samples=2, orbit_trap_enabled=True, orbit_trap_radius=0.25,
+                         julia_c_real=0.5, interior_style=1, stripe_enabled=True)
+    a.add_keyframe(0.0, k0, fr.InterpolationType.Linear)
+    assert a.interpolate(3.0).bailout == 8.0                        # one keyframe -> its state (:84)
+    for it in fr.InterpolationType:
+        b = fr.AnimationSystem()
+        k1 = fr.FractalState(center_x=2.0, zoom=1e-4, max_iterations=1000, palette_mode=5, color_offset=1.0)
+        b.add_keyframe(4.0, k1, it)                                  # added out of order: sorted by time (:16-17)
+        b.add_keyframe(0.0, k0, fr.InterpolationType.Linear)
+        assert [k.time for k in b.get_keyframes()] == [0.0, 4.0]
+        s = b.interpolate(1.0)
+        t = f32(0.25)
+        e = {0: t, 1: f32(2) * t * t, 2: t * t, 3: f32(1) - (f32(1) - t) * (f32(1) - t), 4: t * t}[int(it)]
+        assert s.center_x == float(e) * 2.0                          # easing of the SECOND keyframe (:107)
+        assert s.zoom == pytest.approx(math.exp(float(e) * math.log(1e-4)), rel=1e-15)
+        assert s.max_iterations == (100 if e < f32(0.33) else 550 if e < f32(0.67) else 1000)
+        assert s.palette_mode == (1 if e < f32(0.5) else 5)
+        # taken from key1 (:175-178); everything else reverts to FractalState defaults (:125)
+        assert s.bailout == 8.0 and s.antialiasing_samples == 2 and s.orbit_trap_enabled and s.orbit_trap_radius == 0.25
+        assert s.julia_c_real == float(f32(-0.7)) and s.interior_style == 0 and not s.stripe_enabled
+    # duration grows to time + 1 when a keyframe lands beyond it (:20-22)
+    c = fr.AnimationSystem()
+    assert c.get_duration() == 10.0
+    c.add_keyframe(12.0, k0)
+    assert c.get_duration() == 13.0
+    # negative/zero zoom -> linear interpolation, then the 1e-6 floor (:139-145)
+    d = fr.AnimationSystem()
+    d.add_keyframe(0.0, fr.FractalState(zoom=-1.0), fr.InterpolationType.Linear)
+    d.add_keyframe(2.0, fr.FractalState(zoom=1.0), fr.InterpolationType.Linear)
+    assert d.interpolate(0.5).zoom == 1e-6 and d.interpolate(1.5).zoom == 0.5
+
+
+def test_franim_save_load_round_trip(fr, golden, tmp_path):
+    a = fr.AnimationSystem()
+    assert a.load_from_file(golden["franim"])
+    out = str(tmp_path / "rt.franim")
+    assert a.save_to_file(out)
+    j = json.load(open(out))                                         # valid JSON
+    assert len(j["keyframes"][0]) == 19                              # the writer's 19 keys (:235-255)
+    assert list(j.keys()) == sorted(j.keys()) and list(j["keyframes"][0]) == sorted(j["keyframes"][0])
+    b = fr.AnimationSystem()
+    assert b.load_from_file(out)
+    assert bytes(a.info) == bytes(b.info)
+    for x, y in zip(a.get_keyframes(), b.get_keyframes()):
+        assert x == y                                                # doubles survive the text round trip exactly
+    assert not b.load_from_file(str(tmp_path / "missing.franim"))    # reference: returns false
+
+
+def test_franim_parse_errors(fr, golden):
+    good = json.load(open(golden["franim"]))
+    a = fr.AnimationSystem()
+    for key in ("name", "duration", "loop", "target_fps", "keyframes"):
+        bad = dict(good); del bad[key]
+        with pytest.raises(fr.FractalRendererError) as e:
+            a.loads(json.dumps(bad))
+        assert e.value.status == fr._capi.FR_ERR_PARSE and key in str(e.value)
+    for key in ("time", "interp_type", "center_x", "zoom", "max_iterations", "palette_mode", "color_offset", "color_scale"):
+        bad = json.loads(json.dumps(good)); del bad["keyframes"][2][key]
+        with pytest.raises(fr.FractalRendererError):
+            a.loads(json.dumps(bad))
+    for text in ("", "{", "[1,2]", '{"name": "x",}', '{"name": "\\q"}', "nul"):
+        with pytest.raises(fr.FractalRendererError):
+            a.loads(text)
+    # optional writer keys are honoured; integers given as floats are truncated like nlohmann's get<int>()
+    g = json.loads(json.dumps(good))
+    g["keyframes"][0].update(bailout=6.5, antialiasing_samples=2.9, orbit_trap_enabled=True, color_brightness=1.25,
+                             max_iterations=300.7, rotation_y=1.0)
+    g["name"] = "zürich \"q\"\n"
+    a.loads(json.dumps(g))
+    k = a.get_keyframes()[0].state
+    assert (k.bailout, k.antialiasing_samples, k.orbit_trap_enabled, k.color_brightness, k.max_iterations) == (6.5, 2, True, 1.25, 300)
+    assert a.name == g["name"]
+
+
+def test_animation_renderer_frame_loop(fr, golden):
+    a = fr.AnimationSystem()
+    assert a.load_from_file(golden["franim"])
+    calls = []
+
+    def cb(state, w, h, path):
+        calls.append((state, w, h, path))
+        return len(calls) < 4                                       # 4th frame "fails"
+    r = fr.AnimationRenderer(cb)
+    assert r.start_render(a, "out", frames=range(0, 2400, 1000)) is True
+    assert [c[3] for c in calls] == [os.path.join("out", "frame_%06d.png" % f) for f in (0, 1000, 2000)]
+    assert calls[0][1:3] == (2560, 1440)                            # export size of the animation
+    assert calls[1][0] == a.interpolate(a.frame_time(1000))
+    assert r.start_render(a, "out", frames=range(5)) is False       # callback failure aborts (:109-116)
+    assert fr.AnimationRenderer(None).start_render(a) is False      # no callback set (:207-210)
+    one = fr.AnimationSystem(); one.add_keyframe(0.0, fr.FractalState())
+    assert fr.AnimationRenderer(cb).start_render(one) is False      # needs two keyframes (:35-42)
+
+
+# ---- reference orbit (src/deep_zoom_system.cpp:378-424) ---------------------------------------------------------------
+def test_reference_orbit_matches_oracle(fr, oracle):
+    L = fr.lib()
+    for cx, cy, n in [(-0.5, 0.0, 300), (1.0, 0.0, 100), (0.0, 1.0, 50), (-0.743643887037151, 0.13182590420533, 5000),
+                      (0.3, 0.5, 1000), (-2.0, 0.0, 10), (2.5, 0.0, 10), (1e200, 0.0, 10)]:
+        buf = np.zeros((n, 2)); ln = C.c_int32()
+        assert L.fr_reference_orbit(cx, cy, n, buf.ctypes.data, C.byref(ln)) == 0
+        ref = oracle.reference_orbit(cx, cy, n)
+        assert ln.value == len(ref) and np.array_equal(buf[:ln.value], ref)
+    assert L.fr_reference_orbit(0.0, 0.0, 0, buf.ctypes.data, C.byref(ln)) == fr._capi.FR_ERR_INVALID_ARG
