@@ -35,17 +35,17 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (fractal, precision, W, H, state kwargs)
     "c2": dict(desc="C2 mandelbrot 4096x4096 max_iter=1024 fp64 default viewport (center -0.5,0 zoom 3.0)",
-               fractal="Mandelbrot", precision="F64", W=4096, H=4096, state=dict(max_iterations=1024)),
+               fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=4096, state=dict(max_iterations=1024)),
     "c2_reset": dict(desc="mandelbrot 4096x4096 max_iter=1024 fp64 reset() viewport (zoom 1.5)",
                      fractal="Mandelbrot", precision="F64", W=4096, H=4096, state=dict(max_iterations=1024, zoom=1.5)),
     "c3": dict(desc="C3 julia c=-0.8+0.156i 4096x4096 max_iter=2048 fp32 centre (0,0) zoom 3.0",
-               fractal="JuliaSet", precision="F32", W=4096, H=4096,
+               fractal="JuliaSet", precision="F32", W=4096, H=4096, cpu_rows=4096,
                state=dict(max_iterations=2048, center_x=0.0, center_y=0.0, julia_c_real=-0.8, julia_c_imag=0.156)),
     "c4": dict(desc="C4 deep-zoom mandelbrot 8192x8192 max_iter=16384 fp64 seahorse zoom 1e-6",
-               fractal="Mandelbrot", precision="F64", W=8192, H=8192,
+               fractal="Mandelbrot", precision="F64", W=8192, H=8192, cpu_rows=64,
                state=dict(max_iterations=16384, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-6)),
     "c5": dict(desc="C5 mandelbrot 8192x8192 max_iter=4096 fp64 seahorse zoom 0.008 (one .franim keyframe view)",
-               fractal="Mandelbrot", precision="F64", W=8192, H=8192,
+               fractal="Mandelbrot", precision="F64", W=8192, H=8192, cpu_rows=64,
                state=dict(max_iterations=4096, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.008)),
 }
 
@@ -54,7 +54,7 @@ FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s vector fp64 counts FMA as 2; contr
 FP32_VALU_PEAK_TOPS = 78.6     # 157.3 TFLOP/s / 2
 
 
-def cpu_baseline(workload: dict, budget_rows: int = 1024) -> dict:
+def cpu_baseline(workload: dict) -> dict:
     """Oracle timed on the host cores on evenly spaced row bands of the same frame."""
     from oracle import oracle as O
     O.build()
@@ -63,8 +63,10 @@ def cpu_baseline(workload: dict, budget_rows: int = 1024) -> dict:
     p = O.OracleParams(fractal=0 if w["fractal"] == "Mandelbrot" else 1, precision=1 if w["precision"] == "F64" else 0,
                        **{("max_iterations" if k == "max_iterations" else k): v for k, v in st.items()})
     W, H = w["W"], w["H"]
-    bands, band_rows = 16, max(1, budget_rows // 16)
-    threads = O.max_threads()
+    bands = 16
+    band_rows = max(1, w.get("cpu_rows", 1024) // bands)      # sized for ~10-30 core-seconds of CPU work
+    # the GPU box gives one GPU a 16-CPU share of its host: use that many threads (override: FR_CPU_THREADS)
+    threads = min(O.max_threads(), int(os.environ.get("FR_CPU_THREADS", "16")))
     O.render(p, W, H, y0=0, y1=2, threads=threads, planes=False)          # warm the thread pool
     t0 = time.perf_counter()
     px = 0
@@ -155,8 +157,9 @@ def main() -> None:
         mi = state.max_iterations
         executed = int(torch.where(it < mi, it.to(torch.int64) + 1, torch.full_like(it, mi, dtype=torch.int64)).sum())
         del it
-        stream = torch.cuda.current_stream()
+        stream = torch.cuda.Stream(device=dev)   # a real (non-null) HIP stream: launches AND events go here
         h = stream.cuda_stream
+        assert h != 0
 
         def step(_k):
             r.render(state, W, H, fractal_type=ftype, precision=prec, rgba=rgba, sync=False, stream=h)

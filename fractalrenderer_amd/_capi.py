@@ -78,7 +78,8 @@ SIGNATURES = {
     "fr_render_shard_async": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, _P(fr_shard),
                                         _P(fr_output), C.c_void_p]),
     "fr_ctx_last_kernel_ms": (C.c_float, [C.c_void_p]),
-    "fr_ctx_set_tuning": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "fr_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "fr_ctx_last_grid": (C.c_int, [C.c_void_p]),
     "fr_ctx_compute_units": (C.c_int, [C.c_void_p]),
     "fr_export_rgb8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32]),
     "fr_anim_load": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,9 +28,18 @@ struct fr_ctx {
     uint32_t* d_queue;          /* kShards heads, 128 B apart */
     uint32_t tune_wg_per_cu;    /* 0 = automatic */
     uint32_t tune_run_max;      /* 0 = automatic */
+    uint32_t tune_run_min;      /* 0 = automatic */
+    int tune_shift_bias;        /* added to the guided-run shift */
+    uint32_t tune_pace_cycles;  /* 0 = automatic */
+    uint32_t tune_queue_flags;  /* 0 = automatic, else 0x100 | flags */
+    uint64_t* diag;             /* optional device buffer for per-wave timelines */
+    uint32_t last_grid;
     uint32_t tune_shape;        /* 0 = automatic, else FPW_LOG2 (3, 4, 6) */
     void* scratch;              /* device staging for FR_MEM_HOST outputs */
     size_t scratch_bytes;
+    struct DivCheck { bool valid, julia, f64, ok; uint32_t W, H; };
+    DivCheck div_cache[8];      /* exact_division_ok() results */
+    uint32_t div_next;
 };
 
 #define FR_HIP_TRY(expr)                                                               \
@@ -89,18 +99,44 @@ extern "C" int fr_ctx_compute_units(fr_ctx* c)
     return c->compute_units;
 }
 
-extern "C" int fr_ctx_set_tuning(fr_ctx* c, uint32_t workgroups_per_cu, uint32_t subtiles_per_dequeue)
+/* Tuning / diagnostics knobs by name; value 0 restores the automatic choice. */
+extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
+{
+    if (!c || !name) return fr_set_error(FR_ERR_INVALID_ARG, "ctx/name is NULL");
+    if (!strcmp(name, "workgroups_per_cu")) {
+        if (value < 0 || value > 16) return fr_set_error(FR_ERR_INVALID_ARG, "workgroups_per_cu must be in [0,16]");
+        c->tune_wg_per_cu = (uint32_t)value;
+    } else if (!strcmp(name, "run_max")) {
+        if (value < 0 || value > 1024) return fr_set_error(FR_ERR_INVALID_ARG, "run_max must be in [0,1024]");
+        c->tune_run_max = (uint32_t)value;
+    } else if (!strcmp(name, "run_min")) {
+        if (value < 0 || value > 1024) return fr_set_error(FR_ERR_INVALID_ARG, "run_min must be in [0,1024]");
+        c->tune_run_min = (uint32_t)value;
+    } else if (!strcmp(name, "shift_bias")) {
+        if (value < -16 || value > 16) return fr_set_error(FR_ERR_INVALID_ARG, "shift_bias must be in [-16,16]");
+        c->tune_shift_bias = (int)value;
+    } else if (!strcmp(name, "subtile_shape")) {
+        if (value != 0 && value != 3 && value != 4 && value != 6)
+            return fr_set_error(FR_ERR_INVALID_ARG, "subtile_shape must be 0, 3 (8x8), 4 (16x4) or 6 (64x1)");
+        c->tune_shape = (uint32_t)value;
+    } else if (!strcmp(name, "pace_cycles")) {
+        if (value < 0 || value > (1 << 30)) return fr_set_error(FR_ERR_INVALID_ARG, "pace_cycles out of range");
+        c->tune_pace_cycles = (uint32_t)value;
+    } else if (!strcmp(name, "queue_flags")) {
+        c->tune_queue_flags = (uint32_t)value;         /* 0 = automatic; else 0x100 | kQueueScatter | kQueuePrefetch */
+    } else if (!strcmp(name, "diag_buffer")) {
+        c->diag = (uint64_t*)(uintptr_t)value;        /* device pointer, 4 x u64 per wave of the grid; 0 = off */
+    } else {
+        return fr_set_error(FR_ERR_INVALID_ARG, "unknown option '%s'", name);
+    }
+    return FR_OK;
+}
+
+/* grid size (workgroups of 256 threads) the next render of this geometry would launch */
+extern "C" int fr_ctx_last_grid(fr_ctx* c)
 {
     if (!c) return fr_set_error(FR_ERR_INVALID_ARG, "ctx is NULL");
-    if (workgroups_per_cu > 8) return fr_set_error(FR_ERR_INVALID_ARG, "workgroups_per_cu must be <= 8");
-    /* the top byte of subtiles_per_dequeue selects the sub-tile shape for experiments:
-     * 0 automatic, 3: 8x8, 4: 16x4, 6: 64x1 */
-    c->tune_wg_per_cu = workgroups_per_cu;
-    c->tune_shape = subtiles_per_dequeue >> 24;
-    c->tune_run_max = subtiles_per_dequeue & 0xFFFFFFu;
-    if (c->tune_shape != 0 && c->tune_shape != 3 && c->tune_shape != 4 && c->tune_shape != 6)
-        return fr_set_error(FR_ERR_INVALID_ARG, "unknown sub-tile shape %u", c->tune_shape);
-    return FR_OK;
+    return (int)c->last_grid;
 }
 
 extern "C" float fr_ctx_last_kernel_ms(fr_ctx* c)
@@ -114,6 +150,44 @@ extern "C" float fr_ctx_last_kernel_ms(fr_ctx* c)
 }
 
 /* ---- launch ---------------------------------------------------------------------------------- */
+
+/* The kernels map pixel -> plane coordinate with  q' = fma(a - b*RN(a*y) , y, RN(a*y)),  y = RN(1/b)
+ * instead of the as-written IEEE divide a / b (Markstein's correction step).  That is the
+ * correctly rounded quotient in all but exotic cases; rather than rely on the theorem's side
+ * conditions, evaluate the identical expression here for EVERY numerator the frame uses (one per
+ * column, one per row) and allow the divide-free path only if all of them equal a / b.
+ * Result cached per (W, H, fractal, precision). */
+template <typename T>
+static bool quotients_exact(uint32_t W, uint32_t H, bool julia)
+{
+    const T resx = (T)W, resy = (T)H;
+    const T inv_w = (T)1 / resx, inv_h = (T)1 / resy;
+    auto same = [](T a, T b, T rb) {
+        const T q = a * rb;
+        const T r = std::fma(-q, b, a);
+        return std::fma(r, rb, q) == a / b;
+    };
+    if (julia) {                                   /* shaders/julia.comp:325  uv = pix / size */
+        for (uint32_t x = 0; x < W; ++x) if (!same((T)x, resx, inv_w)) return false;
+        for (uint32_t y = 0; y < H; ++y) if (!same((T)y, resy, inv_h)) return false;
+    } else {                                       /* shaders/mandelbrot.comp:150  (pix - 0.5 res) / res.y */
+        for (uint32_t x = 0; x < W; ++x) if (!same((T)x - (T)0.5 * resx, resy, inv_h)) return false;
+        for (uint32_t y = 0; y < H; ++y) if (!same((T)y - (T)0.5 * resy, resy, inv_h)) return false;
+    }
+    return true;
+}
+
+static bool exact_division_ok(fr_ctx* c, uint32_t W, uint32_t H, bool julia, bool f64)
+{
+    for (int k = 0; k < 8; ++k) {
+        const fr_ctx::DivCheck& d = c->div_cache[k];
+        if (d.valid && d.W == W && d.H == H && d.julia == julia && d.f64 == f64) return d.ok;
+    }
+    const bool ok = f64 ? quotients_exact<double>(W, H, julia) : quotients_exact<float>(W, H, julia);
+    fr_ctx::DivCheck& slot = c->div_cache[c->div_next++ & 7];
+    slot.valid = true; slot.W = W; slot.H = H; slot.julia = julia; slot.f64 = f64; slot.ok = ok;
+    return ok;
+}
 
 template <typename T, int FRACTAL, bool EFFECTS>
 static hipError_t launch_shape(int shape, dim3 grid, hipStream_t s, const LaunchArgs& a)
@@ -175,26 +249,61 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.fast_ok = (B2 >= 4.5 && B2 <= 1e12 && (!julia || c2 <= B2)) ? 1 : 0;
     }
 
+    /* host-prepared reciprocals; the divide-free viewport map is enabled only when verified exact */
+    a.inv_w_d = 1.0 / (double)W;  a.inv_h_d = 1.0 / (double)H;
+    a.inv_w_f = 1.0f / (float)W;  a.inv_h_f = 1.0f / (float)H;
+    a.aspect_d = (double)W / (double)H;
+    a.aspect_f = (float)W / (float)H;
+    a.inv_max_iter = 1.0 / (double)p->max_iterations;
+    a.inv_log2_bailout = 1.0 / log2((double)p->bailout);
+    a.lib_log = !(p->bailout > 1.0f);        /* log2_pos() needs positive arguments: |z|^2 > 1 */
+    a.exact_div_ok = exact_division_ok(c, W, H, julia, f64) ? 1 : 0;
+
     /* sub-tile shape and the tile queue */
     const int shape = c->tune_shape ? (int)c->tune_shape : 3;
     const uint32_t fpw = 1u << shape, fph = 64u >> shape;
     a.nsx = (W + fpw - 1) / fpw;
+    a.nsx_shift = -1;
+    for (int b = 0; b < 31; ++b)
+        if (a.nsx == (1u << b)) a.nsx_shift = b;
     const uint32_t nsy = (rows_local + fph - 1) / fph;
     a.n_sub = a.nsx * nsy;
+    /* blocks of 16 sub-tiles are dealt round-robin to the 8 shards in bit-reversed order over a
+     * power-of-two padded block index space (blocks >= n_blk are skipped by the kernel) */
     const uint32_t nblk = (a.n_sub + kShardBlock - 1) / kShardBlock;
+    uint32_t bits = 1;
+    while ((1u << bits) < nblk) ++bits;
+    const uint32_t padded = 1u << bits;
+    a.n_blk = nblk;
+    a.blk_rev_shift = 32u - bits;
     for (uint32_t k = 0; k < (uint32_t)kShards; ++k)
-        a.shard_len[k] = ((nblk + kShards - 1 - k) / kShards) * kShardBlock;
+        a.shard_len[k] = ((padded + kShards - 1 - k) / kShards) * kShardBlock;
 
-    uint32_t wg_per_cu = c->tune_wg_per_cu ? c->tune_wg_per_cu : 2u;
+    /* The fp64 kernels hold 4 workgroups of 256 threads per CU (VGPR-limited; the per-wave timeline
+     * of the diag buffer shows workgroups beyond that only start when resident ones exit, and find
+     * the queue dry): launch exactly the resident set. */
+    uint32_t wg_per_cu = c->tune_wg_per_cu ? c->tune_wg_per_cu : 4u;
     uint32_t grid = (uint32_t)c->compute_units * wg_per_cu;
     const uint32_t waves_needed = a.n_sub;                 /* never more waves than sub-tiles */
     const uint32_t max_grid = (waves_needed + 3) / 4;
     if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
-    /* guided run length: remaining / (8 * waves per shard), clamped to [1, run_max] */
-    uint32_t waves = grid * 4u, shift = 0;
-    while ((1u << shift) < waves) ++shift;
-    a.run_shift = shift;
-    a.run_max = c->tune_run_max ? c->tune_run_max : 16u;
+    /* Run length of a dequeue = clamp(remaining >> run_shift, run_min, run_max).  Measured on C2
+     * (sweeps in profiles/): sub-tile cost varies 100x (a few iterations outside the set, max_iter
+     * inside), so long runs leave a tail of waves holding several max_iter sub-tiles, while single
+     * sub-tile claims saturate the queue words (~88 dequeues/us each: a 0.44 ms floor).  Short
+     * runs of 2..8 with the divisor at 16 x waves-per-shard measured best. */
+    uint32_t waves_per_shard = (grid * 4u + kShards - 1) / kShards, shift = 0;
+    while ((1u << shift) < 16u * waves_per_shard) ++shift;
+    const int biased = (int)shift + c->tune_shift_bias;
+    a.run_shift = (uint32_t)(biased < 0 ? 0 : (biased > 31 ? 31 : biased));
+    a.run_max = c->tune_run_max ? c->tune_run_max : 8u;
+    a.run_min = c->tune_run_min ? c->tune_run_min : 2u;
+    if (a.run_min > a.run_max) a.run_min = a.run_max;
+    /* cost-paced run length is off unless asked for (pace_cycles > 0): see run_len in the kernel */
+    a.pace_cycles = c->tune_pace_cycles;
+    a.queue_flags = c->tune_queue_flags ? (c->tune_queue_flags & 0xFFu) : kQueuePrefetch;
+    a.diag = c->diag;
+    c->last_grid = grid;
 
     FR_HIP_TRY(hipMemsetAsync(c->d_queue, 0, kShards * kShardStrideWords * sizeof(uint32_t), stream));
     FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
@@ -219,11 +328,20 @@ static int check_common(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, c
 {
     if (!c) return fr_set_error(FR_ERR_INVALID_ARG, "ctx is NULL");
     if (!p || !out) return fr_set_error(FR_ERR_INVALID_ARG, "params/out is NULL");
-    if (!out->rgba && !out->nu && !out->iter)
-        return fr_set_error(FR_ERR_INVALID_ARG, "fr_output has no plane to write");
     int st = fr_params_validate(p, W, H);
     if (st != FR_OK) return st;
     return FR_OK;
+}
+
+/* 1: this part owns rows and has a plane to write; 0: it owns no rows (nothing to do); < 0: error */
+static int check_planes(const fr_shard* shard, uint32_t H, const fr_output* out)
+{
+    if (shard && shard->nparts && shard->part >= shard->nparts)
+        return fr_set_error(FR_ERR_INVALID_ARG, "shard part %u >= nparts %u", shard->part, shard->nparts);
+    if (fr_shard_rows(shard, H) == 0) return 0;
+    if (!out->rgba && !out->nu && !out->iter)
+        return fr_set_error(FR_ERR_INVALID_ARG, "fr_output has no plane to write");
+    return 1;
 }
 
 extern "C" int fr_render_shard_async(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
@@ -233,6 +351,8 @@ extern "C" int fr_render_shard_async(fr_ctx* c, const fr_params* p, uint32_t W, 
     if (st != FR_OK) return st;
     if (out->memory != FR_MEM_DEVICE)
         return fr_set_error(FR_ERR_INVALID_ARG, "fr_render_shard_async needs FR_MEM_DEVICE outputs");
+    st = check_planes(shard, H, out);
+    if (st <= 0) return st;
     FR_HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     return enqueue_render(c, p, W, H, shard, out->rgba, out->nu, out->iter, s);
@@ -243,6 +363,8 @@ extern "C" int fr_render_shard(fr_ctx* c, const fr_params* p, uint32_t W, uint32
 {
     int st = check_common(c, p, W, H, out);
     if (st != FR_OK) return st;
+    st = check_planes(shard, H, out);
+    if (st <= 0) return st;
     FR_HIP_TRY(hipSetDevice(c->device));
 
     if (out->memory == FR_MEM_DEVICE) {

@@ -43,6 +43,8 @@ constexpr int kShards = 8;               /* one queue head per XCD              
 constexpr int kShardStrideWords = 32;    /* 128 B between heads                            */
 constexpr int kShardBlock = 16;          /* sub-tiles are dealt to shards in blocks of 16  */
 constexpr int kFastBlock = 16;           /* iterations per unchecked block                 */
+constexpr uint32_t kQueueScatter = 1u;   /* bit-reversed block order                       */
+constexpr uint32_t kQueuePrefetch = 2u;  /* issue the next dequeue before iterating the current run */
 
 /* Kernel argument block (passed by value; lands in SGPRs / the scalar cache). */
 struct LaunchArgs {
@@ -65,6 +67,16 @@ struct LaunchArgs {
     float brightness, saturation, contrast;
     uint32_t flags;
     int32_t fast_ok;             /* escape is absorbing for every lane (see kernel) */
+    /* host-prepared reciprocals (each the correctly rounded 1/x in the kernel's precision) */
+    int32_t exact_div_ok;        /* div_by() verified == IEEE divide for every column/row of this frame */
+    double inv_w_d, inv_h_d;     /* RN(1/W), RN(1/H) in double */
+    float  inv_w_f, inv_h_f;     /* RN(1/W), RN(1/H) in float  */
+    double aspect_d;             /* (double)W / (double)H */
+    float  aspect_f;             /* (float)W / (float)H   */
+    double inv_max_iter;         /* 1 / max_iter (colour stage only) */
+    double inv_log2_bailout;     /* 1 / log2(bailout) (Julia smooth count) */
+    int32_t nsx_shift;           /* log2(nsx) when nsx is a power of two, else -1 */
+    int32_t lib_log;             /* bailout <= 1: smooth count through the library log(), as written */
     /* outputs */
     float4* rgba;
     void* nu;
@@ -73,9 +85,14 @@ struct LaunchArgs {
     uint32_t* queue;             /* kShards heads, kShardStrideWords apart, zeroed per launch */
     uint32_t n_sub;              /* total sub-tiles                               */
     uint32_t nsx;                /* sub-tiles per sub-tile row                    */
-    uint32_t shard_len[kShards]; /* shard-local index space size                  */
-    uint32_t run_shift;          /* run length = clamp(remaining >> run_shift, 1, run_max) */
-    uint32_t run_max;
+    uint32_t n_blk;              /* blocks of kShardBlock sub-tiles               */
+    uint32_t blk_rev_shift;      /* 32 - ceil(log2(n_blk)): bit-reversal scatter of the block order */
+    uint32_t shard_len[kShards]; /* shard-local index space size (over the padded 2^k blocks) */
+    uint32_t run_shift;          /* run length = clamp(remaining >> run_shift, run_min, run_max) */
+    uint32_t run_max, run_min;
+    uint32_t pace_cycles;        /* target shader cycles of work per dequeue (paced run length) */
+    uint32_t queue_flags;        /* kQueueScatter | kQueuePrefetch */
+    uint64_t* diag;              /* optional: 4 words per wave (t_start, t_end, sub-tiles, claims) */
     fr_palette_table pal;
 };
 
@@ -112,19 +129,69 @@ template <> struct Real<float> {
     static constexpr float ln2() { return 0.693147180559945309417232121458f; }
 };
 
+/* ---- smooth-iteration helpers ---------------------------------------------------------------
+ * The reference writes mu = log(log|z| / log 2) / log 2 (shaders/mandelbrot.comp:174-176), i.e.
+ * log2(log2|z|).  Library log() costs 98 VALU instructions in fp64 on gfx950; the arguments here
+ * are always positive, finite and normal (|z|^2 > bailout^2, and a log2 of it that is > 0), so a
+ * range-reduced atanh series is enough.  Relative error < 4e-16, so nu agrees with the libm
+ * evaluation to ~1e-14 (the parity tests assert 1e-9; the north-star bar is 1e-6). */
+__device__ __forceinline__ double log2_pos(double x)
+{
+    int e = __builtin_amdgcn_frexp_exp(x);              /* x = m * 2^e, m in [0.5, 1) */
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;                                /* m in [sqrt(1/2), sqrt(2)) */
+    e = low ? e - 1 : e;
+    const double s = (m - 1.0) / (m + 1.0);             /* |s| <= 0.1716 */
+    const double z = s * s;
+    /* ln m = 2 s (1 + z/3 + z^2/5 + ... + z^9/19), truncation < 2e-17 */
+    double p = 1.0 / 19.0;
+    p = __builtin_fma(p, z, 1.0 / 17.0);
+    p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, 1.0 / 3.0);
+    p = __builtin_fma(p, z, 1.0);
+    return __builtin_fma(s * p, 2.8853900817779268147 /* 2/ln 2 */, (double)e);
+}
+/* fp32: the hardware log2 (v_log_f32, ~1 ulp), which is also what a GLSL log() lowers to */
+__device__ __forceinline__ float log2_pos(float x) { return __builtin_amdgcn_logf(x); }
+
+/* Correctly rounded a/b from y = RN(1/b) without a divide (Markstein): q = RN(a*y),
+ * r = a - b*q exactly (fma), q' = RN(q + r*y).  The host enables this only after checking, for
+ * every column and row coordinate of the frame, that q' equals the IEEE quotient. */
+template <typename T>
+__device__ __forceinline__ T div_by(T a, T b, T rb)
+{
+    const T q = a * rb;
+    const T r = Real<T>::fma(-q, b, a);
+    return Real<T>::fma(r, rb, q);
+}
+
 /* ---- colour stage (float, as the shaders) ---------------------------------------------- */
 
 __device__ __forceinline__ float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 
-/* get_palette_color for u = fract(t) already taken (shaders/mandelbrot.comp:129-141,
- * shaders/julia.comp:162-181), evaluated from the LDS knot table. */
-__device__ __forceinline__ void palette_eval(const fr_palette_table& pal, float u, float rgb[3])
+/* pow(u, e) for u in [0, 1], e > 0 as exp2(e * log2 u) on the hardware transcendentals -- the
+ * lowering GPU drivers give GLSL pow().  u = 0 -> log2 = -inf -> exp2 = 0. */
+__device__ __forceinline__ float pow01(float u, float e)
 {
+    return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(u));
+}
+
+/* get_palette_color (shaders/mandelbrot.comp:129-141, shaders/julia.comp:162-181), evaluated
+ * from the LDS knot table; like the shader's, its first step is t = fract(t). */
+__device__ __forceinline__ void palette_eval(const fr_palette_table& pal, float t, float rgb[3])
+{
+    const float u = t - floorf(t);
     const int warp = pal.warp;
     if (warp == FR_WARP_GRAY) { rgb[0] = rgb[1] = rgb[2] = u; return; }
     float w = u;
     if (warp == FR_WARP_POW) {
-        w = powf(u, pal.warp_exp);
+        w = pow01(u, pal.warp_exp);
     } else if (warp == FR_WARP_SMOOTHSTEP) {
         float s = clamp01((u - 0.0f) / (1.0f - 0.0f));
         w = s * s * (3.0f - 2.0f * s);
@@ -143,6 +210,11 @@ __device__ __forceinline__ void palette_eval(const fr_palette_table& pal, float 
     const float* b = pal.knot[seg + 1];
     for (int c = 0; c < 3; ++c) rgb[c] = a[c] * (1.0f - k) + b[c] * k;   /* GLSL mix */
 }
+
+/* Narrowing of the palette argument: fp32 hands t to the palette untouched (the shader);
+ * fp64 reduces with fract() in double first so the narrowing keeps the fractional part. */
+__device__ __forceinline__ float pal_arg(float t) { return t; }
+__device__ __forceinline__ float pal_arg(double t) { return (float)(t - ::floor(t)); }
 
 __device__ __forceinline__ float aces(float x)
 {
@@ -165,7 +237,7 @@ __device__ __forceinline__ void post_chain(float rgb[3], float brightness, float
     for (int k = 0; k < 3; ++k) c[k] = (c[k] - 0.5f) * contrast + 0.5f;
     const float gray = c[0] * 0.299f + c[1] * 0.587f + c[2] * 0.114f;
     for (int k = 0; k < 3; ++k) c[k] = clamp01(gray * (1.0f - saturation) + c[k] * saturation);
-    for (int k = 0; k < 3; ++k) rgb[k] = powf(aces(c[k]), 1.0f / 2.2f);
+    for (int k = 0; k < 3; ++k) rgb[k] = pow01(aces(c[k]), 1.0f / 2.2f);
 }
 
 /* ---- XCD id ------------------------------------------------------------------------------ */
@@ -334,17 +406,35 @@ escape_kernel(const LaunchArgs A)
     const T bailout = (T)S.bailout;
     const T B2 = bailout * bailout;
     const T resx = (T)W, resy = (T)H;
+    const T inv_w = sizeof(T) == 8 ? (T)A.inv_w_d : (T)A.inv_w_f;
+    const T inv_h = sizeof(T) == 8 ? (T)A.inv_h_d : (T)A.inv_h_f;
+    const T aspect = sizeof(T) == 8 ? (T)A.aspect_d : (T)A.aspect_f;      /* shaders/julia.comp:221 */
+    const T inv_max_iter = (T)A.inv_max_iter;
+    const T inv_log2_bailout = (T)A.inv_log2_bailout;
+    /* planes nobody asked for are not computed (wave-uniform branches) */
+    const bool want_rgb = A.rgba != nullptr;
+    const bool want_nu = want_rgb || A.nu != nullptr;
+    (void)inv_w; (void)aspect; (void)inv_log2_bailout;
 
     /* ---- persistent loop over the sharded tile queue ---- */
     uint32_t shard = xcc_id();
     uint32_t tried = 0;              /* shards found dry so far */
     uint32_t seen = 0;               /* last head value observed on `shard` */
 
+    /* Run length of one dequeue.  Two bounds:
+     *   guided  : remaining >> run_shift  -- longer runs first, run_min sub-tiles at the end of a shard;
+     *   paced   : (optional, pace_cycles > 0) pace_cycles / measured cycles per sub-tile of this wave's
+     *             previous run -- a wave in a cheap region claims many sub-tiles per atomic, a wave in the
+     *             set's interior one.  Only useful with the un-scattered order, where consecutive runs
+     *             of a shard are spatial neighbours; measured no better than short fixed runs on C2. */
+    const bool pacing = A.pace_cycles != 0;
+    uint32_t paced = pacing ? A.run_min : 0xFFFFFFFFu;      /* until the first run has been timed */
     auto run_len = [&](uint32_t sh, uint32_t seen_head) -> uint32_t {
         const uint32_t len = A.shard_len[sh];
         const uint32_t rem = seen_head < len ? len - seen_head : 0u;
         uint32_t n = rem >> A.run_shift;
-        n = n < 1u ? 1u : n;
+        n = n > paced ? paced : n;
+        n = n < A.run_min ? A.run_min : n;
         return n > A.run_max ? A.run_max : n;
     };
     auto claim = [&](uint32_t sh, uint32_t n) -> uint32_t {
@@ -352,6 +442,11 @@ escape_kernel(const LaunchArgs A)
         if (lane == 0) v = atomicAdd(&A.queue[sh * kShardStrideWords], n);
         return v;
     };
+
+    const uint32_t wave_id = blockIdx.x * (kBlockThreads / kWave) + (threadIdx.x >> 6);
+    uint64_t diag_t0 = 0;
+    uint32_t diag_subtiles = 0, diag_claims = 0;
+    if (A.diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
 
     uint32_t cur_n = run_len(shard, seen);
     uint32_t cur_raw = claim(shard, cur_n);
@@ -361,6 +456,7 @@ escape_kernel(const LaunchArgs A)
         uint32_t count = cur_n;
         const uint32_t cur_shard = shard;
         const uint32_t len = A.shard_len[cur_shard];
+        ++diag_claims;
         if (begin >= len) {
             /* home shard dry: steal from the next one; exit after all 8 are dry */
             if (++tried >= (uint32_t)kShards) break;
@@ -372,21 +468,36 @@ escape_kernel(const LaunchArgs A)
         }
         if (begin + count > len) count = len - begin;
         seen = begin + count;
-        /* issue the next dequeue now; it is consumed after this run's arithmetic */
-        const uint32_t next_n = run_len(shard, seen);
-        const uint32_t next_raw = claim(shard, next_n);
+        /* prefetch: issue the next dequeue now; it is consumed after this run's arithmetic (hides
+         * the dequeue latency, but commits this wave to one more run) */
+        const bool prefetch = (A.queue_flags & kQueuePrefetch) != 0;
+        uint32_t next_n = 0, next_raw = 0;
+        if (prefetch) { next_n = run_len(shard, seen); next_raw = claim(shard, next_n); }
+        const uint64_t run_t0 = pacing ? __builtin_readcyclecounter() : 0ull;
+        diag_subtiles += count;
 
         for (uint32_t j = begin; j < begin + count; ++j) {
             /* shard-local index -> global sub-tile id (blocks of kShardBlock dealt round-robin) */
-            const uint32_t sid = ((j / kShardBlock) * kShards + cur_shard) * kShardBlock + (j % kShardBlock);
+            /* ... and the dealt blocks are SCATTERED over the frame (bit-reversed block index): rows
+             * far from the set cost a few iterations per pixel and are bound by the dequeue latency,
+             * rows through it cost max_iter and are bound by VALU issue; scattering keeps both kinds
+             * in flight on every SIMD at all times instead of one phase after the other. */
+            const uint32_t dealt = (j / kShardBlock) * kShards + cur_shard;
+            const uint32_t blk = (A.queue_flags & kQueueScatter) ? __builtin_bitreverse32(dealt) >> A.blk_rev_shift : dealt;
+            if (blk >= A.n_blk) continue;
+            const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
             if (sid >= A.n_sub) continue;
-            const uint32_t sty = sid / A.nsx, stx = sid - sty * A.nsx;
+            const uint32_t sty = A.nsx_shift >= 0 ? sid >> A.nsx_shift : sid / A.nsx;
+            const uint32_t stx = sid - sty * A.nsx;
             const int px = (int)stx * FPW + lx;
             const int lrow = (int)sty * FPH + ly;               /* row inside this part's packed rows */
             const bool inside = px < W && lrow < A.rows_local;
             /* packed local row -> frame row (row strips dealt round-robin to parts) */
-            const int strip = lrow / A.rows_per_strip;
-            const int py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
+            int py = lrow;
+            if (A.nparts != 1) {
+                const int strip = lrow / A.rows_per_strip;
+                py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
+            }
             const uint64_t outside_mask = __builtin_amdgcn_ballot_w64(!inside);
 
             float acc[3] = {0.0f, 0.0f, 0.0f};
@@ -396,15 +507,22 @@ escape_kernel(const LaunchArgs A)
             const int nsamp = aa * aa;
             for (int s = 0; s < nsamp; ++s) {
                 int it;
-                T nu;
-                float rgb[3];
+                T nu = T(0);
+                float rgb[3] = {0.0f, 0.0f, 0.0f};
                 if constexpr (FRACTAL == 0) {
                     /* shaders/mandelbrot.comp:222-226 sample offsets, :149-151 viewport map */
-                    const int sy = s / aa, sx = s - sy * aa;
-                    const T pxs = (T)px + (T)sx / (T)aa;
-                    const T pys = (T)py + (T)sy / (T)aa;
-                    const T uvx = (pxs - T(0.5) * resx) / resy;
-                    const T uvy = (pys - T(0.5) * resy) / resy;
+                    T uvx, uvy;
+                    if (aa == 1 && A.exact_div_ok) {
+                        /* same quotients as the as-written divides, without the divide (div_by) */
+                        uvx = div_by<T>((T)px - T(0.5) * resx, resy, inv_h);
+                        uvy = div_by<T>((T)py - T(0.5) * resy, resy, inv_h);
+                    } else {
+                        const int sy = s / aa, sx = s - sy * aa;
+                        const T pxs = (T)px + (T)sx / (T)aa;
+                        const T pys = (T)py + (T)sy / (T)aa;
+                        uvx = (pxs - T(0.5) * resx) / resy;
+                        uvy = (pys - T(0.5) * resy) / resy;
+                    }
                     const T cx = center_x + uvx * zoom;
                     const T cy = center_y + uvy * zoom;
                     if constexpr (!EFFECTS) {
@@ -416,20 +534,22 @@ escape_kernel(const LaunchArgs A)
                          * retires the lane at i = 0 anyway; fast_ok also needs B^2 >= 4.5 */
                         T r2;
                         escape_run<T>(o, B2, max_iter, A.fast_ok != 0, outside_mask, it, r2);
-                        nu = (T)it;                                           /* :172 */
-                        if (it < max_iter) {                                  /* :173-177 */
-                            const T log_zn = Real<T>::log(r2) / T(2);
-                            const T mu = Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
-                            nu = (T)it + T(1) - mu;
+                        if (want_nu) {
+                            nu = (T)it;                                       /* :172 */
+                            if (it < max_iter) {                              /* :173-177: mu = log2(log2|z|) */
+                                if (!A.lib_log) {
+                                    nu = (T)it + T(1) - log2_pos(T(0.5) * log2_pos(r2));
+                                } else {
+                                    const T log_zn = Real<T>::log(r2) / T(2);
+                                    nu = (T)it + T(1) - Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
+                                }
+                            }
                         }
-                        T t = nu / (T)max_iter * (T)S.color_scale;            /* :179 */
-                        t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
-                        if (it >= max_iter && A.interior_style == 1) {        /* :182-183 */
-                            rgb[0] = rgb[1] = rgb[2] = 0.0f;
-                        } else {                                              /* :190 */
-                            T u = t + (T)S.color_offset;
-                            u = u - Real<T>::floor(u);
-                            palette_eval(S.pal, (float)u, rgb);
+                        if (want_rgb) {
+                            T t = nu * inv_max_iter * (T)S.color_scale;       /* :179 */
+                            t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
+                            if (!(it >= max_iter && A.interior_style == 1))   /* :182-183, :190 */
+                                palette_eval(S.pal, pal_arg(t + (T)S.color_offset), rgb);
                         }
                     } else {
                         T zx = T(0), zy = T(0), ezx, ezy, min_trap;
@@ -445,19 +565,15 @@ escape_kernel(const LaunchArgs A)
                         t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
                         bool coloured = false;
                         if (it >= max_iter) {                                 /* :182-188 */
-                            if (A.interior_style == 1) { rgb[0] = rgb[1] = rgb[2] = 0.0f; coloured = true; }
+                            if (A.interior_style == 1) { coloured = true; }
                             else if (A.interior_style == 2) {
                                 const float tf = expf(-(float)min_trap * 6.0f / fmaxf(S.trap_radius, 1e-6f));
-                                float u = S.color_offset + tf * 0.3f;
-                                u = u - floorf(u);
-                                palette_eval(S.pal, u, rgb);
+                                palette_eval(S.pal, S.color_offset + tf * 0.3f, rgb);
                                 coloured = true;
                             }
                         }
                         if (!coloured) {
-                            T u = t + (T)S.color_offset;
-                            u = u - Real<T>::floor(u);
-                            palette_eval(S.pal, (float)u, rgb);
+                            palette_eval(S.pal, pal_arg(t + (T)S.color_offset), rgb);
                             if (A.trap_enabled) {                             /* :193-198 */
                                 const float r = fmaxf(S.trap_radius, 1e-6f);
                                 const float tf = expf(-(float)min_trap * 4.0f / r);
@@ -476,16 +592,21 @@ escape_kernel(const LaunchArgs A)
                     }
                 } else {
                     /* shaders/julia.comp:325 uv, :221-225 z0, :253-259 sample offsets (sx outer) */
-                    T uvx = (T)px / resx, uvy = (T)py / resy;
-                    if (aa > 1) {
-                        const int sx = s / aa, sy = s - sx * aa;
-                        const T pixel_size = T(1) / resx;
-                        const T sample_offset = pixel_size / (T)aa;
-                        const T centre = sample_offset * (T)(aa - 1) * T(0.5);
-                        uvx = uvx + ((T)sx * sample_offset - centre) / resx;
-                        uvy = uvy + ((T)sy * sample_offset - centre) / resy;
+                    T uvx, uvy;
+                    if (aa == 1 && A.exact_div_ok) {
+                        uvx = div_by<T>((T)px, resx, inv_w);
+                        uvy = div_by<T>((T)py, resy, inv_h);
+                    } else {
+                        uvx = (T)px / resx; uvy = (T)py / resy;
+                        if (aa > 1) {
+                            const int sx = s / aa, sy = s - sx * aa;
+                            const T pixel_size = T(1) / resx;
+                            const T sample_offset = pixel_size / (T)aa;
+                            const T centre = sample_offset * (T)(aa - 1) * T(0.5);
+                            uvx = uvx + ((T)sx * sample_offset - centre) / resx;
+                            uvy = uvy + ((T)sy * sample_offset - centre) / resy;
+                        }
                     }
-                    const T aspect = resx / resy;
                     const T z0x = center_x + (uvx - T(0.5)) * zoom * aspect;
                     const T z0y = center_y + (uvy - T(0.5)) * zoom;
                     Orbit<T> o;
@@ -497,15 +618,20 @@ escape_kernel(const LaunchArgs A)
                     o.y2d = o.Yd * o.Yd;
                     T r2;
                     escape_run<T>(o, B2, max_iter, A.fast_ok != 0, outside_mask, it, r2);
-                    if (it < max_iter) {                                      /* :237-248 */
-                        nu = (T)it + T(1) - Real<T>::log(Real<T>::log(r2) / (T)S.log_bailout) / Real<T>::ln2();
-                        T t = nu / (T)max_iter;
-                        t = (T)S.color_offset + t * (T)S.color_scale;
-                        t = t - Real<T>::floor(t);
-                        palette_eval(S.pal, (float)t, rgb);
-                    } else {                                                  /* :243-244 */
-                        nu = (T)max_iter;
-                        rgb[0] = rgb[1] = rgb[2] = 0.0f;
+                    if (want_nu) {
+                        nu = (T)max_iter;                                     /* :243-244 interior: black */
+                        if (it < max_iter) {                                  /* :237-248 */
+                            /* log(log(r2)/log(B))/log 2 == log2(log2(r2) / log2(B)) */
+                            if (!A.lib_log)
+                                nu = (T)it + T(1) - log2_pos(log2_pos(r2) * inv_log2_bailout);
+                            else
+                                nu = (T)it + T(1) - Real<T>::log(Real<T>::log(r2) / (T)S.log_bailout) / Real<T>::ln2();
+                            if (want_rgb) {
+                                T t = nu * inv_max_iter;
+                                t = (T)S.color_offset + t * (T)S.color_scale;
+                                palette_eval(S.pal, pal_arg(t), rgb);
+                            }
+                        }
                     }
                 }
                 if (s == 0) { first_nu = nu; first_it = it; }
@@ -516,7 +642,7 @@ escape_kernel(const LaunchArgs A)
                 const float n = (float)(aa * aa);
                 acc[0] /= n; acc[1] /= n; acc[2] /= n;
             }
-            if (A.flags & FR_FLAG_POST_CHAIN)
+            if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                 post_chain(acc, S.brightness, S.saturation, S.contrast, FRACTAL == 1);
 
             if (inside) {
@@ -527,8 +653,19 @@ escape_kernel(const LaunchArgs A)
             }
         }
 
+        if (pacing) {   /* pace the claim after next from this run's measured cost (wave-uniform) */
+            const uint32_t dt = (uint32_t)(__builtin_readcyclecounter() - run_t0) | 1u;
+            const float want = (float)A.pace_cycles * (float)count * __builtin_amdgcn_rcpf((float)dt);
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)fminf(want, 1024.0f));
+            paced = n < 1u ? 1u : n;
+        }
+        if (!prefetch) { next_n = run_len(shard, seen); next_raw = claim(shard, next_n); }
         cur_raw = next_raw;
         cur_n = next_n;
+    }
+    if (A.diag && lane == 0) {      /* diagnostics: per-wave timeline (100 MHz ticks) and work counts */
+        uint64_t* d = A.diag + (size_t)wave_id * 4;
+        d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = diag_subtiles; d[3] = diag_claims;
     }
 }
 

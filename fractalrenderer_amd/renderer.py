@@ -78,10 +78,20 @@ class Renderer:
     def compute_units(self) -> int:
         return _capi.check(self._lib.fr_ctx_compute_units(self._ctx))
 
-    def set_tuning(self, workgroups_per_cu: int = 0, subtiles_per_dequeue: int = 0, shape: int = 0) -> None:
-        """shape: 0 automatic, 3: 8x8 sub-tiles, 4: 16x4, 6: 64x1"""
-        _capi.check(self._lib.fr_ctx_set_tuning(self._ctx, workgroups_per_cu,
-                                                (shape << 24) | (subtiles_per_dequeue & 0xFFFFFF)))
+    def set_option(self, name: str, value: int) -> None:
+        """fr_ctx_set_option: queue tuning / diagnostics by name (0 = automatic)."""
+        _capi.check(self._lib.fr_ctx_set_option(self._ctx, name.encode(), int(value)))
+
+    def set_tuning(self, workgroups_per_cu: int = 0, subtiles_per_dequeue: int = 0, shape: int = 0,
+                   run_min: int = 0, shift_bias: int = 0, pace_cycles: int = 0) -> None:
+        """All queue knobs at once; 0 = automatic everywhere (see fr_ctx_set_option)."""
+        for k, v in (("workgroups_per_cu", workgroups_per_cu), ("run_max", subtiles_per_dequeue),
+                     ("subtile_shape", shape), ("run_min", run_min), ("shift_bias", shift_bias),
+                     ("pace_cycles", pace_cycles)):
+            self.set_option(k, v)
+
+    def last_grid(self) -> int:
+        return _capi.check(self._lib.fr_ctx_last_grid(self._ctx))
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.fr_ctx_last_kernel_ms(self._ctx))
@@ -138,6 +148,9 @@ class Renderer:
         """
         p = state.to_params(fractal_type, precision, post_chain)
         rows = shard.rows(height) if shard else height
+        if rows == 0:
+            _capi.check(self._lib.fr_params_validate(C.byref(p), width, height))
+            return                                   # this part owns no rows of the frame
         out = self._output(precision, rows, width, rgba, nu, iter)
         sh = shard.to_c() if shard else None
         shp = C.byref(sh) if sh is not None else None

@@ -191,10 +191,20 @@ int fr_render_shard_async(fr_ctx* ctx, const fr_params* p, uint32_t width, uint3
  * < 0 if nothing was rendered yet. */
 float fr_ctx_last_kernel_ms(fr_ctx* ctx);
 
-/* Tuning knobs of the persistent tile queue (defaults are picked per launch from
- * the frame size and max_iterations): workgroups per CU and sub-tiles per dequeue.
- * 0 restores the automatic choice. */
-int fr_ctx_set_tuning(fr_ctx* ctx, uint32_t workgroups_per_cu, uint32_t subtiles_per_dequeue);
+/* Tuning / diagnostic options of the persistent tile queue, by name; value 0 restores the
+ * automatic choice (made per launch from the frame geometry).  Names:
+ *   "workgroups_per_cu"  workgroups of 256 threads launched per compute unit
+ *   "run_max", "run_min" longest / shortest run of sub-tiles one dequeue may claim
+ *   "shift_bias"         signed change of log2 of the guided-run divisor
+ *   "pace_cycles"        shader cycles of work a dequeue aims to claim (cost-paced run length)
+ *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1
+ *   "diag_buffer"        device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks,
+ *                        sub-tiles processed, dequeues); 0 disables
+ * None of them can change a pixel (tests/test_gpu_parity.py::test_tuning_variants_are_bit_identical). */
+int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
+
+/* Workgroups launched by the most recent render on this context. */
+int fr_ctx_last_grid(fr_ctx* ctx);
 
 /* Number of compute units of the context's device (hipDeviceProp_t.multiProcessorCount). */
 int fr_ctx_compute_units(fr_ctx* ctx);

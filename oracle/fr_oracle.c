@@ -159,7 +159,9 @@ void fro_post_chain(float rgb[3], float brightness, float saturation, float cont
 #define FLOOR floorf
 #define ATAN2 atan2f
 #define SIN sinf
+#define PAL_ARG(t) (t)
 #include "fr_oracle_sample.inc"
+#undef PAL_ARG
 #undef FN
 #undef REAL
 #undef LOG
@@ -179,7 +181,9 @@ void fro_post_chain(float rgb[3], float brightness, float saturation, float cont
 #define FLOOR floor
 #define ATAN2 atan2
 #define SIN sin
+#define PAL_ARG(t) ((float)((t) - floor(t)))
 #include "fr_oracle_sample.inc"
+#undef PAL_ARG
 #undef FN
 #undef REAL
 #undef LOG
