@@ -19,18 +19,28 @@
 
 using namespace fr;
 
+static constexpr int kMaxStages = 16;
+static constexpr size_t kCtrlWords = (size_t)2 * kMaxStages * kShards * kShardStrideWords;
+
 struct fr_ctx {
     int device;
     int compute_units;
     hipStream_t stream;
     hipEvent_t ev_begin, ev_end;
     bool have_timing;
-    uint32_t* d_queue;          /* kShards heads, 128 B apart */
+    uint32_t* d_ctrl;           /* queue heads + stream counters of every stage (kCtrlWords) */
+    void* stream_buf[2];        /* ping-pong survivor streams */
+    size_t stream_bytes;
+    uint32_t tune_staging;      /* 0 = automatic (currently off), 1 = off (single pass), 2 = on */
+    uint32_t tune_stage_first;  /* first budget b0 (0 = 32) */
+    uint32_t tune_stage_ratio;  /* budget growth per stage (0 = 4) */
+    uint32_t tune_stream_run_max, tune_stream_run_min, tune_stream_wg_per_cu;
+    size_t diag_stride;         /* words between the diag regions of consecutive stages */
+    int last_stages;
     uint32_t tune_wg_per_cu;    /* 0 = automatic */
     uint32_t tune_run_max;      /* 0 = automatic */
     uint32_t tune_run_min;      /* 0 = automatic */
     int tune_shift_bias;        /* added to the guided-run shift */
-    uint32_t tune_pace_cycles;  /* 0 = automatic */
     uint32_t tune_queue_flags;  /* 0 = automatic, else 0x100 | flags */
     uint64_t* diag;             /* optional device buffer for per-wave timelines */
     uint32_t last_grid;
@@ -72,7 +82,7 @@ extern "C" int fr_ctx_create(int device_ordinal, fr_ctx** out)
     if ((e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_begin)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_end)) != hipSuccess ||
-        (e2 = hipMalloc((void**)&c->d_queue, kShards * kShardStrideWords * sizeof(uint32_t))) != hipSuccess) {
+        (e2 = hipMalloc((void**)&c->d_ctrl, kCtrlWords * sizeof(uint32_t))) != hipSuccess) {
         free(c);
         return fr_set_error(FR_ERR_HIP, "context setup failed: %s", hipGetErrorString(e2));
     }
@@ -86,7 +96,8 @@ extern "C" void fr_ctx_destroy(fr_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
-    (void)hipFree(c->d_queue);
+    (void)hipFree(c->d_ctrl);
+    for (int k = 0; k < 2; ++k) if (c->stream_buf[k]) (void)hipFree(c->stream_buf[k]);
     (void)hipEventDestroy(c->ev_begin);
     (void)hipEventDestroy(c->ev_end);
     (void)hipStreamDestroy(c->stream);
@@ -119,9 +130,26 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         if (value != 0 && value != 3 && value != 4 && value != 6)
             return fr_set_error(FR_ERR_INVALID_ARG, "subtile_shape must be 0, 3 (8x8), 4 (16x4) or 6 (64x1)");
         c->tune_shape = (uint32_t)value;
-    } else if (!strcmp(name, "pace_cycles")) {
-        if (value < 0 || value > (1 << 30)) return fr_set_error(FR_ERR_INVALID_ARG, "pace_cycles out of range");
-        c->tune_pace_cycles = (uint32_t)value;
+    } else if (!strcmp(name, "staging")) {
+        if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "staging must be 0 (automatic), 1 (off) or 2 (on)");
+        c->tune_staging = (uint32_t)value;
+    } else if (!strcmp(name, "stage_first")) {
+        if (value < 0 || value > (1 << 24)) return fr_set_error(FR_ERR_INVALID_ARG, "stage_first out of range");
+        c->tune_stage_first = (uint32_t)value;
+    } else if (!strcmp(name, "stage_ratio")) {
+        if (value != 0 && (value < 2 || value > 64)) return fr_set_error(FR_ERR_INVALID_ARG, "stage_ratio must be 0 or in [2,64]");
+        c->tune_stage_ratio = (uint32_t)value;
+    } else if (!strcmp(name, "stream_run_max")) {
+        if (value < 0 || value > 1024) return fr_set_error(FR_ERR_INVALID_ARG, "stream_run_max must be in [0,1024]");
+        c->tune_stream_run_max = (uint32_t)value;
+    } else if (!strcmp(name, "stream_run_min")) {
+        if (value < 0 || value > 1024) return fr_set_error(FR_ERR_INVALID_ARG, "stream_run_min must be in [0,1024]");
+        c->tune_stream_run_min = (uint32_t)value;
+    } else if (!strcmp(name, "stream_workgroups_per_cu")) {
+        if (value < 0 || value > 8) return fr_set_error(FR_ERR_INVALID_ARG, "stream_workgroups_per_cu must be in [0,8]");
+        c->tune_stream_wg_per_cu = (uint32_t)value;
+    } else if (!strcmp(name, "diag_stride")) {
+        c->diag_stride = (size_t)value;               /* u64 words between the diag regions of consecutive stages */
     } else if (!strcmp(name, "queue_flags")) {
         c->tune_queue_flags = (uint32_t)value;         /* 0 = automatic; else 0x100 | kQueueScatter | kQueuePrefetch */
     } else if (!strcmp(name, "diag_buffer")) {
@@ -132,11 +160,11 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
     return FR_OK;
 }
 
-/* grid size (workgroups of 256 threads) the next render of this geometry would launch */
+/* workgroups of 256 threads per launch of the most recent render; bits 16.. = number of stages */
 extern "C" int fr_ctx_last_grid(fr_ctx* c)
 {
     if (!c) return fr_set_error(FR_ERR_INVALID_ARG, "ctx is NULL");
-    return (int)c->last_grid;
+    return (int)(c->last_grid | ((uint32_t)c->last_stages << 16));
 }
 
 extern "C" float fr_ctx_last_kernel_ms(fr_ctx* c)
@@ -190,15 +218,35 @@ static bool exact_division_ok(fr_ctx* c, uint32_t W, uint32_t H, bool julia, boo
 }
 
 template <typename T, int FRACTAL, bool EFFECTS>
-static hipError_t launch_shape(int shape, dim3 grid, hipStream_t s, const LaunchArgs& a)
+static hipError_t launch_tile(int shape, dim3 grid, hipStream_t s, const LaunchArgs& a)
 {
     switch (shape) {
-    case 6: hipLaunchKernelGGL((escape_kernel<T, FRACTAL, 6, EFFECTS>), grid, dim3(kBlockThreads), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((escape_kernel<T, FRACTAL, 4, EFFECTS>), grid, dim3(kBlockThreads), 0, s, a); break;
-    default: hipLaunchKernelGGL((escape_kernel<T, FRACTAL, 3, EFFECTS>), grid, dim3(kBlockThreads), 0, s, a); break;
+    case 6: hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 6, EFFECTS>), grid, dim3(kBlockThreads), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 4, EFFECTS>), grid, dim3(kBlockThreads), 0, s, a); break;
+    default: hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 3, EFFECTS>), grid, dim3(kBlockThreads), 0, s, a); break;
     }
     return hipGetLastError();
 }
+
+template <typename T, int FRACTAL>
+static hipError_t launch_stream(dim3 grid, hipStream_t s, const LaunchArgs& a)
+{
+    hipLaunchKernelGGL((stream_kernel<T, FRACTAL>), grid, dim3(kBlockThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+static uint32_t ceil_log2(uint32_t v)
+{
+    uint32_t b = 0;
+    while ((1u << b) < v && b < 31) ++b;
+    return b;
+}
+
+/* control block in device memory, zeroed by ONE memset per render:
+ *   words [s * 256, s * 256 + 256): the 8 queue heads of stage s (128 B apart)
+ *   words [(kMaxStages + s) * 256, +256): the 8 region counters of the survivor stream written by stage s */
+static uint32_t* stage_heads(fr_ctx* c, int s) { return c->d_ctrl + (size_t)s * kShards * kShardStrideWords; }
+static uint32_t* stage_counter(fr_ctx* c, int s) { return c->d_ctrl + (size_t)(kMaxStages + s) * kShards * kShardStrideWords; }
 
 static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* shard,
                           float* rgba, void* nu, int32_t* iter, hipStream_t stream)
@@ -216,6 +264,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const bool julia = p->fractal_type == FR_FRACTAL_JULIA;
     const bool f64 = p->precision == FR_PRECISION_F64;
     const bool effects = !julia && (p->orbit_trap_enabled || p->stripe_enabled || p->interior_style == 2);
+    const int max_iter = p->max_iterations;
 
     LaunchArgs a;
     memset(&a, 0, sizeof(a));
@@ -223,7 +272,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.julia_cx = p->julia_c_real; a.julia_cy = p->julia_c_imag;
     a.bailout = p->bailout;
     a.log_bailout = f64 ? log((double)p->bailout) : (double)logf(p->bailout);
-    a.max_iter = p->max_iterations;
+    a.max_iter = max_iter;
     a.W = (int32_t)W; a.H = (int32_t)H;
     a.rows_local = (int32_t)rows_local;
     a.part = (int32_t)norm.part; a.nparts = (int32_t)norm.nparts; a.rows_per_strip = (int32_t)norm.rows_per_strip;
@@ -237,7 +286,6 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.flags = p->flags;
     a.rgba = reinterpret_cast<float4*>(rgba);
     a.nu = nu; a.iter = iter;
-    a.queue = c->d_queue;
     fr_palette_table_build(julia ? 1 : 0, p->palette_mode, &a.pal);
 
     /* escape is absorbing (see escape_run): bailout^2 in [4.5, 1e12], and for Julia |c| <= bailout;
@@ -254,73 +302,161 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.inv_w_f = 1.0f / (float)W;  a.inv_h_f = 1.0f / (float)H;
     a.aspect_d = (double)W / (double)H;
     a.aspect_f = (float)W / (float)H;
-    a.inv_max_iter = 1.0 / (double)p->max_iterations;
+    a.inv_max_iter = 1.0 / (double)max_iter;
     a.inv_log2_bailout = 1.0 / log2((double)p->bailout);
     a.lib_log = !(p->bailout > 1.0f);        /* log2_pos() needs positive arguments: |z|^2 > 1 */
     a.exact_div_ok = exact_division_ok(c, W, H, julia, f64) ? 1 : 0;
 
-    /* sub-tile shape and the tile queue */
+    /* ---- stage schedule: iteration budgets b0 < b1 < ... < max_iter -------------------------------
+     * tile pass runs [0, b0), stream pass k runs [b_{k-1}, b_k).  Default b0 = 32, x4 per stage.
+     * Not staged: SSAA (samples of a pixel must meet again to be averaged), the effects variant
+     * (needs min_trap along the whole orbit), short max_iter. */
+    int bounds[kMaxStages];
+    int nstage = 0;
+    {
+        /* measured (profiles/r01_staging_sweeps.txt): the single pass is faster on C2/C3/C4, staging wins
+         * only on C5 (+9 %); it stays opt-in ("staging" = 2) until the per-stage tails are gone */
+        const bool allow = !effects && p->antialiasing_samples <= 1 && c->tune_staging == 2;
+        const int first = c->tune_stage_first ? (int)c->tune_stage_first : 32;
+        const int ratio = c->tune_stage_ratio >= 2 ? (int)c->tune_stage_ratio : 4;
+        if (allow && max_iter >= 2 * first) {
+            long long b = first - first % kFastBlock;            /* budgets are multiples of the unchecked block */
+            if (b < kFastBlock) b = kFastBlock;
+            while (b < max_iter && nstage < kMaxStages - 1) { bounds[nstage++] = (int)b; b *= ratio; }
+            /* do not leave a last stage much shorter than the one before it */
+            if (nstage >= 2 && max_iter - bounds[nstage - 1] < bounds[nstage - 1] / 4) --nstage;
+        }
+        bounds[nstage++] = max_iter;
+    }
+    const bool staged = nstage > 1;
+
+    /* ---- geometry of the tile pass -------------------------------------------------------------- */
     const int shape = c->tune_shape ? (int)c->tune_shape : 3;
     const uint32_t fpw = 1u << shape, fph = 64u >> shape;
-    a.nsx = (W + fpw - 1) / fpw;
-    a.nsx_shift = -1;
+    QueueArgs tq;
+    memset(&tq, 0, sizeof(tq));
+    tq.nsx = (W + fpw - 1) / fpw;
+    tq.nsx_shift = -1;
     for (int b = 0; b < 31; ++b)
-        if (a.nsx == (1u << b)) a.nsx_shift = b;
+        if (tq.nsx == (1u << b)) tq.nsx_shift = b;
     const uint32_t nsy = (rows_local + fph - 1) / fph;
-    a.n_sub = a.nsx * nsy;
-    /* blocks of 16 sub-tiles are dealt round-robin to the 8 shards in bit-reversed order over a
-     * power-of-two padded block index space (blocks >= n_blk are skipped by the kernel) */
-    const uint32_t nblk = (a.n_sub + kShardBlock - 1) / kShardBlock;
-    uint32_t bits = 1;
-    while ((1u << bits) < nblk) ++bits;
-    const uint32_t padded = 1u << bits;
-    a.n_blk = nblk;
-    a.blk_rev_shift = 32u - bits;
-    for (uint32_t k = 0; k < (uint32_t)kShards; ++k)
-        a.shard_len[k] = ((padded + kShards - 1 - k) / kShards) * kShardBlock;
+    tq.n_items = tq.nsx * nsy;
+    /* blocks of 16 sub-tiles are dealt round-robin to the 8 shards over a power-of-two padded block
+     * index space (optionally bit-reversed; blocks >= n_blk are skipped by the kernel) */
+    tq.n_blk = (tq.n_items + kShardBlock - 1) / kShardBlock;
+    uint32_t bits = ceil_log2(tq.n_blk);
+    if (bits < 1) bits = 1;
+    tq.n_blk_padded = 1u << bits;
+    tq.blk_rev_shift = 32u - bits;
 
     /* The fp64 kernels hold 4 workgroups of 256 threads per CU (VGPR-limited; the per-wave timeline
      * of the diag buffer shows workgroups beyond that only start when resident ones exit, and find
      * the queue dry): launch exactly the resident set. */
-    uint32_t wg_per_cu = c->tune_wg_per_cu ? c->tune_wg_per_cu : 4u;
+    const uint32_t wg_per_cu = c->tune_wg_per_cu ? c->tune_wg_per_cu : 4u;
     uint32_t grid = (uint32_t)c->compute_units * wg_per_cu;
-    const uint32_t waves_needed = a.n_sub;                 /* never more waves than sub-tiles */
-    const uint32_t max_grid = (waves_needed + 3) / 4;
+    const uint32_t max_grid = (tq.n_items + 3) / 4;        /* never more waves than sub-tiles */
     if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
-    /* Run length of a dequeue = clamp(remaining >> run_shift, run_min, run_max).  Measured on C2
-     * (sweeps in profiles/): sub-tile cost varies 100x (a few iterations outside the set, max_iter
-     * inside), so long runs leave a tail of waves holding several max_iter sub-tiles, while single
-     * sub-tile claims saturate the queue words (~88 dequeues/us each: a 0.44 ms floor).  Short
-     * runs of 2..8 with the divisor at 16 x waves-per-shard measured best. */
-    uint32_t waves_per_shard = (grid * 4u + kShards - 1) / kShards, shift = 0;
-    while ((1u << shift) < 16u * waves_per_shard) ++shift;
-    const int biased = (int)shift + c->tune_shift_bias;
-    a.run_shift = (uint32_t)(biased < 0 ? 0 : (biased > 31 ? 31 : biased));
-    a.run_max = c->tune_run_max ? c->tune_run_max : 8u;
-    a.run_min = c->tune_run_min ? c->tune_run_min : 2u;
-    if (a.run_min > a.run_max) a.run_min = a.run_max;
-    /* cost-paced run length is off unless asked for (pace_cycles > 0): see run_len in the kernel */
-    a.pace_cycles = c->tune_pace_cycles;
-    a.queue_flags = c->tune_queue_flags ? (c->tune_queue_flags & 0xFFu) : kQueuePrefetch;
-    a.diag = c->diag;
+    const uint32_t waves_per_shard = (grid * 4u + kShards - 1) / kShards;
+    auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
+    /* Run length of a dequeue = clamp(remaining >> run_shift, run_min, run_max).
+     *  - single pass (measured on C2, profiles/r01_sweep_c2.txt): sub-tile cost varies 100x, so long
+     *    runs leave a tail of waves holding several max_iter sub-tiles while single sub-tile claims
+     *    saturate the queue words (~88 dequeues/us each: a 0.44 ms floor): short runs of 2..8;
+     *  - staged tile pass: every sub-tile costs at most b0 iterations, so long runs are safe and
+     *    hide the dequeue latency that dominates cheap sub-tiles. */
+    if (staged) {
+        tq.run_shift = clamp_shift((int)ceil_log2(2u * waves_per_shard));
+        tq.run_max = c->tune_run_max ? c->tune_run_max : 32u;
+        tq.run_min = c->tune_run_min ? c->tune_run_min : 4u;
+    } else {
+        tq.run_shift = clamp_shift((int)ceil_log2(16u * waves_per_shard));
+        tq.run_max = c->tune_run_max ? c->tune_run_max : 8u;
+        tq.run_min = c->tune_run_min ? c->tune_run_min : 2u;
+    }
+    if (tq.run_min > tq.run_max) tq.run_min = tq.run_max;
+    tq.flags = c->tune_queue_flags ? (c->tune_queue_flags & 0xFFu) : kQueuePrefetch;
     c->last_grid = grid;
 
-    FR_HIP_TRY(hipMemsetAsync(c->d_queue, 0, kShards * kShardStrideWords * sizeof(uint32_t), stream));
+    /* ---- survivor streams (ping-pong) in context scratch ------------------------------------------ */
+    const size_t nfields = julia ? 2 : 4;
+    const size_t block_bytes = 64 * 4 + nfields * 64 * (f64 ? 8 : 4);
+    /* the stream kernel holds 6 workgroups per CU (57 VGPRs, SGPR-limited); its blocks are latency
+     * bound (dequeue -> record loads -> iterate -> scattered stores), so run all of them */
+    const uint32_t sgrid = (uint32_t)c->compute_units * (c->tune_stream_wg_per_cu ? c->tune_stream_wg_per_cu : 6u);
+    const size_t npx = (size_t)rows_local * W;
+    /* worst case: every sample survives (npx/64 full blocks) + one partial block per wave; the 8
+     * regions of a stream hold 1.5x that, so a region that fills up can spill into its neighbours */
+    const uint32_t worst_blocks = (uint32_t)((npx + 63) / 64) + (grid > sgrid ? grid : sgrid) * 4u + 16u;
+    const uint32_t region_blocks = (worst_blocks * 3u / 2u + kShards - 1) / kShards + 1u;
+    const uint32_t cap_blocks = region_blocks * kShards;
+    if (staged) {
+        const size_t need = (size_t)cap_blocks * block_bytes;
+        if (need > c->stream_bytes) {
+            /* grow-only; happens on the first render of a larger geometry (not capturable) */
+            for (int k = 0; k < 2; ++k) {
+                if (c->stream_buf[k]) { (void)hipFree(c->stream_buf[k]); c->stream_buf[k] = nullptr; }
+            }
+            c->stream_bytes = 0;
+            FR_HIP_TRY(hipMalloc(&c->stream_buf[0], need));
+            FR_HIP_TRY(hipMalloc(&c->stream_buf[1], need));
+            c->stream_bytes = need;
+        }
+    }
+
+    FR_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, kCtrlWords * sizeof(uint32_t), stream));
     FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
+
+    /* ---- tile pass ---------------------------------------------------------------------------------- */
+    a.q = tq;
+    a.q.heads = stage_heads(c, 0);
+    a.i0 = 0;
+    a.i1 = bounds[0];
+    if (staged) {
+        a.out.base = (uint8_t*)c->stream_buf[0];
+        a.out.n_blocks = stage_counter(c, 0);
+        a.out.region_blocks = region_blocks;
+    }
+    a.diag = c->diag;
     hipError_t e;
     if (julia) {
-        e = f64 ? launch_shape<double, 1, false>(shape, dim3(grid), stream, a)
-                : launch_shape<float, 1, false>(shape, dim3(grid), stream, a);
+        e = f64 ? launch_tile<double, 1, false>(shape, dim3(grid), stream, a)
+                : launch_tile<float, 1, false>(shape, dim3(grid), stream, a);
     } else if (effects) {
-        e = f64 ? launch_shape<double, 0, true>(shape, dim3(grid), stream, a)
-                : launch_shape<float, 0, true>(shape, dim3(grid), stream, a);
+        e = f64 ? launch_tile<double, 0, true>(shape, dim3(grid), stream, a)
+                : launch_tile<float, 0, true>(shape, dim3(grid), stream, a);
     } else {
-        e = f64 ? launch_shape<double, 0, false>(shape, dim3(grid), stream, a)
-                : launch_shape<float, 0, false>(shape, dim3(grid), stream, a);
+        e = f64 ? launch_tile<double, 0, false>(shape, dim3(grid), stream, a)
+                : launch_tile<float, 0, false>(shape, dim3(grid), stream, a);
     }
-    if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString(e));
+
+    /* ---- stream passes ------------------------------------------------------------------------------ */
+    for (int k = 1; k < nstage; ++k) {
+        a.i0 = bounds[k - 1];
+        a.i1 = bounds[k];
+        a.in.base = (uint8_t*)c->stream_buf[(k - 1) & 1];
+        a.in.n_blocks = stage_counter(c, k - 1);
+        a.in.region_blocks = region_blocks;
+        a.out.base = (uint8_t*)c->stream_buf[k & 1];
+        a.out.n_blocks = stage_counter(c, k);
+        a.out.region_blocks = region_blocks;
+        memset(&a.q, 0, sizeof(a.q));
+        a.q.heads = stage_heads(c, k);
+        /* a block of 64 records costs at most (i1 - i0) iterations: uniform, claim a few at a time */
+        const uint32_t swps = (sgrid * 4u + kShards - 1) / kShards;
+        a.q.run_shift = clamp_shift((int)ceil_log2(2u * swps));
+        a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 16u;
+        a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 2u;
+        if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
+        a.q.flags = tq.flags & kQueuePrefetch;
+        a.diag = c->diag ? c->diag + (size_t)k * c->diag_stride : nullptr;
+        if (julia) e = f64 ? launch_stream<double, 1>(dim3(sgrid), stream, a) : launch_stream<float, 1>(dim3(sgrid), stream, a);
+        else       e = f64 ? launch_stream<double, 0>(dim3(sgrid), stream, a) : launch_stream<float, 0>(dim3(sgrid), stream, a);
+        if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "stream kernel launch failed: %s", hipGetErrorString(e));
+    }
     FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
     c->have_timing = true;
+    c->last_stages = nstage;
     return FR_OK;
 }
 

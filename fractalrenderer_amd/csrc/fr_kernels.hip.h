@@ -6,27 +6,33 @@
  * palette), in fp32 (what the reference does) or fp64.  How it is computed is
  * MI355X-first and shares nothing with the reference's 16x16-workgroup GLSL dispatch:
  *
- *   - one wavefront lane per pixel; a wave owns a "sub-tile" of 64 pixels
- *     (8x8, 16x4 or 64x1 -- every lane row is a whole number of 128-byte lines of the
- *     row-major RGBA-f32 frame, so stores are full-line coalesced);
- *   - a PERSISTENT grid (CUs x k workgroups) pulls runs of sub-tiles from a tile queue
- *     sharded per XCD (8 heads, 128 B apart), with guided run lengths (long runs first,
- *     single sub-tiles at the end) and stealing from the other XCDs' shards when the
- *     home shard is dry; the next dequeue is issued before the current run is iterated,
- *     so its latency hides under the arithmetic;
- *   - the iteration index is wave-uniform and lives in SGPRs; a lane that escapes
- *     records (i, |z|^2) and is parked at the fixed point z = 0, c = 0, so no per-lane
- *     "active" predicate exists in the loop; the wave leaves the loop as soon as the
- *     ballot of escaped lanes is full (wave-uniform early-out);
- *   - the arithmetic is the reference's, one rounding per operation, NO contraction of
- *     the as-written a*b+c (file is built with -ffp-contract=off).  Where an fma is
- *     written explicitly it multiplies by an exact power of two, which rounds exactly
- *     like the as-written two-operation form (see "scaled-imaginary form" below);
- *   - the palette knot table and the viewport constants are staged once per workgroup
- *     into LDS; every lane reads them from there (broadcast ds_reads).
+ *   - TILE PASS (tile_kernel): one wavefront lane per pixel; a wave owns a "sub-tile" of 64
+ *     pixels (8x8, 16x4 or 64x1 -- every lane row is a whole number of 128-byte lines of the
+ *     row-major RGBA-f32 frame, so stores are full-line coalesced).  A PERSISTENT grid pulls runs
+ *     of sub-tiles from a tile queue sharded per XCD (8 heads, 128 B apart), stealing from the
+ *     other shards when the home shard is dry; the next dequeue is issued before the current run
+ *     is iterated.
+ *   - STAGES.  Sub-tile cost varies 100x (a few iterations outside the set, max_iter inside) and a
+ *     64-pixel wave runs as long as its slowest lane (25 % lane occupancy on a Julia dust).  So the
+ *     tile pass only runs the first S0 iterations; pixels still alive are COMPACTED -- through a
+ *     per-wave LDS ring into dense blocks of 64 survivor records {pixel, z, c} in HBM -- and a
+ *     STREAM PASS (stream_kernel) continues them, 64 live lanes per wave, up to the next budget
+ *     (x4 per stage), compacting again, until max_iter.  Every stage's work items have bounded,
+ *     similar cost: long latency-hiding runs are safe in the cheap tile pass, the expensive passes
+ *     are dense and balance by count.
+ *   - the iteration index is wave-uniform and lives in SGPRs; a lane that escapes records
+ *     (i, |z|^2) and is parked at the fixed point z = 0, c = 0, so no per-lane "active" predicate
+ *     exists in the loop; the wave leaves the loop as soon as the ballot of finished lanes is full
+ *     (wave-uniform early-out);
+ *   - the arithmetic is the reference's, one rounding per operation, NO contraction of the
+ *     as-written a*b+c (file is built with -ffp-contract=off).  Where an fma is written explicitly
+ *     it multiplies by an exact power of two, which rounds exactly like the as-written
+ *     two-operation form (see "scaled-imaginary form" below);
+ *   - the palette knot table and the viewport constants are staged once per workgroup into LDS;
+ *     every lane reads them from there (broadcast ds_reads).
  *
- * There is no dense contraction in this path: no MFMA.  The bound is fp64 (fp32) VALU
- * issue; HBM traffic is the write-once 16 B/pixel output.
+ * There is no dense contraction in this path: no MFMA.  The bound is fp64 (fp32) VALU issue; HBM
+ * traffic is the write-once 16 B/pixel output plus 36 B per survivor record per stage.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -39,12 +45,39 @@ namespace fr {
 
 constexpr int kWave = 64;
 constexpr int kBlockThreads = 256;
+constexpr int kWavesPerBlock = kBlockThreads / kWave;
 constexpr int kShards = 8;               /* one queue head per XCD                        */
 constexpr int kShardStrideWords = 32;    /* 128 B between heads                            */
 constexpr int kShardBlock = 16;          /* sub-tiles are dealt to shards in blocks of 16  */
 constexpr int kFastBlock = 16;           /* iterations per unchecked block                 */
 constexpr uint32_t kQueueScatter = 1u;   /* bit-reversed block order                       */
 constexpr uint32_t kQueuePrefetch = 2u;  /* issue the next dequeue before iterating the current run */
+constexpr uint32_t kInvalidPixel = 0xFFFFFFFFu;
+constexpr int kRingSlots = 128;          /* survivor ring capacity per wave (records)      */
+
+/* One survivor stream in device scratch: blocks of 64 records, each block laid out
+ * [pixel u32 x64][X x64][Yd x64]([cx x64][cyd x64] for Mandelbrot), so every field is one
+ * coalesced access per wave. */
+struct StreamRef {
+    uint8_t* base;               /* kShards regions of region_blocks blocks each */
+    uint32_t* n_blocks;          /* kShards device counters, kShardStrideWords apart: blocks appended per region */
+    uint32_t region_blocks;      /* capacity of one region; 8 regions hold 1.5x the worst-case total */
+    uint32_t pad_;
+};
+
+/* Queue geometry of one launch. */
+struct QueueArgs {
+    uint32_t* heads;             /* kShards words, kShardStrideWords apart, zeroed per render */
+    uint32_t n_items;            /* sub-tiles (tile pass); stream pass reads its count from the stream */
+    uint32_t nsx;                /* sub-tiles per sub-tile row                    */
+    int32_t  nsx_shift;          /* log2(nsx) when nsx is a power of two, else -1 */
+    uint32_t n_blk;              /* blocks of kShardBlock sub-tiles               */
+    uint32_t n_blk_padded;       /* n_blk rounded up to a power of two (index space the shards deal from) */
+    uint32_t blk_rev_shift;      /* 32 - log2(n_blk_padded): bit-reversal scatter of the block order */
+    uint32_t run_shift;          /* run length = clamp(remaining >> run_shift, run_min, run_max) */
+    uint32_t run_max, run_min;
+    uint32_t flags;              /* kQueueScatter | kQueuePrefetch */
+};
 
 /* Kernel argument block (passed by value; lands in SGPRs / the scalar cache). */
 struct LaunchArgs {
@@ -66,7 +99,7 @@ struct LaunchArgs {
     int32_t stripe_enabled; float stripe_density;
     float brightness, saturation, contrast;
     uint32_t flags;
-    int32_t fast_ok;             /* escape is absorbing for every lane (see kernel) */
+    int32_t fast_ok;             /* escape is absorbing for every lane (see escape_run) */
     /* host-prepared reciprocals (each the correctly rounded 1/x in the kernel's precision) */
     int32_t exact_div_ok;        /* div_by() verified == IEEE divide for every column/row of this frame */
     double inv_w_d, inv_h_d;     /* RN(1/W), RN(1/H) in double */
@@ -75,24 +108,16 @@ struct LaunchArgs {
     float  aspect_f;             /* (float)W / (float)H   */
     double inv_max_iter;         /* 1 / max_iter (colour stage only) */
     double inv_log2_bailout;     /* 1 / log2(bailout) (Julia smooth count) */
-    int32_t nsx_shift;           /* log2(nsx) when nsx is a power of two, else -1 */
     int32_t lib_log;             /* bailout <= 1: smooth count through the library log(), as written */
+    /* stage: this launch runs iterations [i0, i1); i1 < max_iter -> unfinished pixels go to `out` */
+    int32_t i0, i1;
+    StreamRef in, out;
     /* outputs */
     float4* rgba;
     void* nu;
     int32_t* iter;
-    /* tile queue */
-    uint32_t* queue;             /* kShards heads, kShardStrideWords apart, zeroed per launch */
-    uint32_t n_sub;              /* total sub-tiles                               */
-    uint32_t nsx;                /* sub-tiles per sub-tile row                    */
-    uint32_t n_blk;              /* blocks of kShardBlock sub-tiles               */
-    uint32_t blk_rev_shift;      /* 32 - ceil(log2(n_blk)): bit-reversal scatter of the block order */
-    uint32_t shard_len[kShards]; /* shard-local index space size (over the padded 2^k blocks) */
-    uint32_t run_shift;          /* run length = clamp(remaining >> run_shift, run_min, run_max) */
-    uint32_t run_max, run_min;
-    uint32_t pace_cycles;        /* target shader cycles of work per dequeue (paced run length) */
-    uint32_t queue_flags;        /* kQueueScatter | kQueuePrefetch */
-    uint64_t* diag;              /* optional: 4 words per wave (t_start, t_end, sub-tiles, claims) */
+    QueueArgs q;
+    uint64_t* diag;              /* optional: 4 words per wave (t_start, t_end, items, dequeues) */
     fr_palette_table pal;
 };
 
@@ -104,6 +129,20 @@ struct LdsBlock {
     float brightness, saturation, contrast;
     int32_t max_iter, W, H, aa;
 };
+
+__device__ __forceinline__ void stage_constants(LdsBlock& S, const LaunchArgs& A)
+{
+    if (threadIdx.x == 0) {
+        S.pal = A.pal;
+        S.center_x = A.center_x; S.center_y = A.center_y; S.zoom = A.zoom;
+        S.julia_cx = A.julia_cx; S.julia_cy = A.julia_cy; S.log_bailout = A.log_bailout;
+        S.bailout = A.bailout; S.color_offset = A.color_offset; S.color_scale = A.color_scale;
+        S.trap_radius = A.trap_radius; S.stripe_density = A.stripe_density;
+        S.brightness = A.brightness; S.saturation = A.saturation; S.contrast = A.contrast;
+        S.max_iter = A.max_iter; S.W = A.W; S.H = A.H; S.aa = A.aa;
+    }
+    __syncthreads();
+}
 
 template <typename T> struct Real;
 template <> struct Real<double> {
@@ -240,6 +279,51 @@ __device__ __forceinline__ void post_chain(float rgb[3], float brightness, float
     for (int k = 0; k < 3; ++k) rgb[k] = pow01(aces(c[k]), 1.0f / 2.2f);
 }
 
+/* Smooth count + colour of one finished sample (no trap/stripe effects).  `it` is the escape
+ * index, it >= max_iter for a sample that never escaped.
+ * Mandelbrot: shaders/mandelbrot.comp:172-190; Julia: shaders/julia.comp:237-248. */
+template <typename T, int FRACTAL>
+__device__ __forceinline__ void shade(const LaunchArgs& A, const LdsBlock& S, const int it, const T r2,
+                                      const bool want_nu, const bool want_rgb, T& nu, float rgb[3])
+{
+    const int max_iter = S.max_iter;
+    const T inv_max_iter = (T)A.inv_max_iter;
+    nu = T(0);
+    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+    if (!want_nu) return;
+    if constexpr (FRACTAL == 0) {
+        nu = (T)max_iter;                                             /* :172 */
+        if (it < max_iter) {                                          /* :173-177: mu = log2(log2|z|) */
+            if (!A.lib_log) {
+                nu = (T)it + T(1) - log2_pos(T(0.5) * log2_pos(r2));
+            } else {
+                const T log_zn = Real<T>::log(r2) / T(2);
+                nu = (T)it + T(1) - Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
+            }
+        }
+        if (want_rgb) {
+            T t = nu * inv_max_iter * (T)S.color_scale;               /* :179 */
+            t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
+            if (!(it >= max_iter && A.interior_style == 1))           /* :182-183, :190 */
+                palette_eval(S.pal, pal_arg(t + (T)S.color_offset), rgb);
+        }
+    } else {
+        nu = (T)max_iter;                                             /* :243-244 interior: black */
+        if (it < max_iter) {                                          /* :237-248 */
+            /* log(log(r2)/log(B))/log 2 == log2(log2(r2) / log2(B)) */
+            if (!A.lib_log)
+                nu = (T)it + T(1) - log2_pos(log2_pos(r2) * (T)A.inv_log2_bailout);
+            else
+                nu = (T)it + T(1) - Real<T>::log(Real<T>::log(r2) / (T)S.log_bailout) / Real<T>::ln2();
+            if (want_rgb) {
+                T t = nu * inv_max_iter;
+                t = (T)S.color_offset + t * (T)S.color_scale;
+                palette_eval(S.pal, pal_arg(t), rgb);
+            }
+        }
+    }
+}
+
 /* ---- XCD id ------------------------------------------------------------------------------ */
 __device__ __forceinline__ uint32_t xcc_id()
 {
@@ -247,6 +331,166 @@ __device__ __forceinline__ uint32_t xcc_id()
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return v & 7u;      /* speed hint only: picks the home shard, never correctness */
 }
+
+/* ---- XCD-sharded work queue ------------------------------------------------------------------
+ * 8 heads, one per XCD.  A wave claims a run of items from its home shard with one atomicAdd,
+ * run length clamp(remaining >> run_shift, run_min, run_max); when a shard is dry it moves to
+ * the next one and returns false after all 8 were found dry (every wave reaches that).  With
+ * kQueuePrefetch the next claim is issued when a run is handed out, so its latency hides under the
+ * run's arithmetic (at the price of committing the wave to one more run). */
+struct WaveQueue {
+    uint32_t* heads;
+    uint32_t n_groups, group;     /* groups dealt round-robin: shard k owns groups k, k+8, ... of `group` items */
+    const uint32_t* len_words;    /* or: per-shard lengths in memory (kShardStrideWords apart), capped at len_cap */
+    uint32_t len_cap;
+    uint32_t run_shift, run_min, run_max;
+    uint32_t lane;
+    uint32_t shard, tried, seen;
+    uint32_t cur_n, cur_raw, next_n, next_raw;
+    bool prefetch, started, pending;
+
+    __device__ __forceinline__ uint32_t shard_len(uint32_t sh) const
+    {
+        if (len_words) {
+            const uint32_t v = len_words[sh * kShardStrideWords];      /* uniform address: scalar load */
+            return v < len_cap ? v : len_cap;
+        }
+        return ((n_groups + (uint32_t)kShards - 1u - sh) / (uint32_t)kShards) * group;
+    }
+    __device__ __forceinline__ uint32_t run_len(uint32_t sh, uint32_t seen_head) const
+    {
+        const uint32_t l = shard_len(sh);
+        const uint32_t rem = seen_head < l ? l - seen_head : 0u;
+        uint32_t n = rem >> run_shift;
+        n = n < run_min ? run_min : n;
+        return n > run_max ? run_max : n;
+    }
+    __device__ __forceinline__ uint32_t claim(uint32_t sh, uint32_t n) const
+    {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&heads[sh * kShardStrideWords], n);
+        return v;
+    }
+    __device__ __forceinline__ void init(uint32_t* h, uint32_t groups, uint32_t group_items, uint32_t shift,
+                                         uint32_t rmin, uint32_t rmax, bool pf, uint32_t ln)
+    {
+        heads = h;
+        n_groups = groups; group = group_items; len_words = nullptr; len_cap = 0;
+        run_shift = shift; run_min = rmin; run_max = rmax; prefetch = pf; lane = ln;
+        shard = xcc_id(); tried = 0; seen = 0;
+        cur_n = cur_raw = next_n = next_raw = 0;
+        started = false; pending = false;
+    }
+    __device__ __forceinline__ void init_lengths(uint32_t* h, const uint32_t* lengths, uint32_t cap, uint32_t shift,
+                                                 uint32_t rmin, uint32_t rmax, bool pf, uint32_t ln)
+    {
+        init(h, 0, 1, shift, rmin, rmax, pf, ln);
+        len_words = lengths; len_cap = cap;
+    }
+    /* hands out the next run [begin, begin+count) of shard `sh`; false = no work left anywhere */
+    __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& count, uint32_t& sh)
+    {
+        if (pending) { cur_n = next_n; cur_raw = next_raw; }
+        else { cur_n = run_len(shard, seen); cur_raw = claim(shard, cur_n); }
+        pending = false;
+        started = true;
+        for (;;) {
+            const uint32_t b = __builtin_amdgcn_readfirstlane(cur_raw);
+            const uint32_t l = shard_len(shard);
+            if (b >= l) {
+                if (++tried >= (uint32_t)kShards) return false;
+                shard = (shard + 1u) & (uint32_t)(kShards - 1);
+                seen = 0;
+                cur_n = run_len(shard, seen);
+                cur_raw = claim(shard, cur_n);
+                continue;
+            }
+            uint32_t c = cur_n;
+            if (b + c > l) c = l - b;
+            seen = b + c;
+            begin = b; count = c; sh = shard;
+            if (prefetch) { next_n = run_len(shard, seen); next_raw = claim(shard, next_n); pending = true; }
+            return true;
+        }
+    }
+};
+
+/* ---- survivor ring ---------------------------------------------------------------------------
+ * A wave's unfinished samples are appended to a ring in LDS (wave-private: DS operations of one
+ * wave execute in order, no barrier needed); whenever 64 are queued, lane l takes record head+l
+ * and the wave writes one dense, fully coalesced block to the output stream.  Block indices come
+ * from one atomicAdd per 64 records, claimed one block ahead so the latency never shows. */
+template <typename T, int NF>
+struct WaveRing {
+    uint32_t pix[kRingSlots];
+    T f[NF][kRingSlots];
+};
+
+template <typename T, int NF>
+struct RingWriter {
+    WaveRing<T, NF>* ring;
+    StreamRef out;
+    uint32_t lane;
+    uint32_t head, tail;          /* wave-uniform record counters */
+    uint32_t home;                /* region this wave appends to (its XCD) */
+
+    static constexpr size_t kBlockBytes = 64 * 4 + (size_t)NF * 64 * sizeof(T);
+
+    __device__ __forceinline__ void init(WaveRing<T, NF>* r, const StreamRef& o, uint32_t ln)
+    {
+        ring = r; out = o; lane = ln; head = tail = 0; home = xcc_id();
+    }
+    /* one block of the home region (one atomicAdd on the region's counter: 8 counters share the
+     * load); a full region spills to the next one -- the 8 regions together hold 1.5x the worst case */
+    __device__ __forceinline__ bool take_block(uint32_t& region, uint32_t& blk)
+    {
+        for (uint32_t t = 0; t < (uint32_t)kShards; ++t) {
+            region = (home + t) & (uint32_t)(kShards - 1);
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(&out.n_blocks[region * kShardStrideWords], 1u);
+            blk = __builtin_amdgcn_readfirstlane(v);
+            if (blk < out.region_blocks) return true;
+        }
+        return false;                                      /* cannot happen: capacity is worst-case x 1.5 */
+    }
+    __device__ __forceinline__ void write_block(uint32_t nvalid)
+    {
+        uint32_t region, blk;
+        if (!take_block(region, blk)) { head += nvalid; return; }
+        const uint32_t slot = (head + lane) & (kRingSlots - 1);
+        const bool valid = lane < nvalid;
+        uint8_t* b = out.base + ((size_t)region * out.region_blocks + blk) * kBlockBytes;
+        reinterpret_cast<uint32_t*>(b)[lane] = valid ? ring->pix[slot] : kInvalidPixel;
+        T* fields = reinterpret_cast<T*>(b + 64 * 4);
+#pragma unroll
+        for (int k = 0; k < NF; ++k) fields[k * 64 + lane] = valid ? ring->f[k][slot] : T(0);
+        head += nvalid;
+    }
+    /* append the lanes with `keep` set; v[] are the record fields */
+    __device__ __forceinline__ void append(bool keep, uint32_t pixel, const T (&v)[NF])
+    {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        if (m == 0ull) return;
+        const uint32_t n = (uint32_t)__builtin_popcountll(m);
+        if (keep) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t slot = (tail + rank) & (kRingSlots - 1);
+            ring->pix[slot] = pixel;
+#pragma unroll
+            for (int k = 0; k < NF; ++k) ring->f[k][slot] = v[k];
+        }
+        tail += n;
+        __builtin_amdgcn_wave_barrier();
+        if (tail - head >= 64u) write_block(64u);
+        __builtin_amdgcn_wave_barrier();
+    }
+    /* end of kernel: flush the partial block (the only not-full block a wave ever writes) */
+    __device__ __forceinline__ void finish()
+    {
+        const uint32_t left = tail - head;
+        if (left > 0u) write_block(left);
+    }
+};
 
 /* ---- one escape-time run over a wave's 64 samples -------------------------------------------
  *
@@ -292,22 +536,23 @@ __device__ __forceinline__ T orbit_r2(const Orbit<T>& o)
     return Real<T>::fma(T(0.25), o.y2d, o.x2);
 }
 
-/* Runs the wave's 64 orbits to completion.  esc_i: escape index (max_iter if never),
- * esc_r2: |z|^2 at escape.  done_in: lanes that must not run (outside the frame). */
+/* Runs the wave's 64 orbits over iterations [i0, i1).  esc_i: escape index, i1 if the lane is
+ * still alive after update i1-1 (its orbit state is then the state after i1 updates);
+ * esc_r2: |z|^2 at escape.  done_in: lanes that must not run (outside the frame / empty). */
 template <typename T>
-__device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int max_iter,
-                                           const bool fast_ok, const uint64_t done_in,
+__device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0, const int i1,
+                                           const bool fast_ok, const bool start_fast, const uint64_t done_in,
                                            int& esc_i, T& esc_r2)
 {
-    esc_i = max_iter;
+    esc_i = i1;
     esc_r2 = T(0);
     uint64_t done = done_in;
-    int i = 0;                       /* wave-uniform: SGPR */
-    bool fast = false;
+    int i = i0;                      /* wave-uniform: SGPR */
+    bool fast = start_fast && fast_ok;
 
-    while (i < max_iter) {
-        if (done == ~0ull) break;    /* every lane escaped: wave-uniform early-out */
-        const int left = max_iter - i;
+    while (i < i1) {
+        if (done == ~0ull) break;    /* every lane finished: wave-uniform early-out */
+        const int left = i1 - i;
         if (fast && left >= kFastBlock) {
             const Orbit<T> snap = o;
 #pragma unroll
@@ -372,27 +617,32 @@ __device__ __forceinline__ void escape_run_effects(T& zx, T& zy, const T cx, con
     esc_zx = zx; esc_zy = zy;
 }
 
-/* ---- the kernel ------------------------------------------------------------------------------
+template <int FRACTAL> struct RecFields { static constexpr int n = FRACTAL == 0 ? 4 : 2; };
+
+__device__ __forceinline__ void diag_write(const LaunchArgs& A, uint32_t lane, uint64_t t0, uint32_t items, uint32_t claims)
+{
+    if (A.diag && lane == 0) {      /* diagnostics: per-wave timeline (100 MHz ticks) and work counts */
+        const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+        uint64_t* d = A.diag + (size_t)wave_id * 4;
+        d[0] = t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = items; d[3] = claims;
+    }
+}
+
+/* ---- tile pass ---------------------------------------------------------------------------------
  * FRACTAL: 0 Mandelbrot, 1 Julia.  FPW_LOG2: log2 of the sub-tile width (3: 8x8, 4: 16x4, 6: 64x1).
- * EFFECTS: trap / stripe / interior-style-2 variant (Mandelbrot only). */
+ * EFFECTS: trap / stripe / interior-style-2 variant (Mandelbrot only, never staged).
+ * Runs iterations [0, A.i1); when A.i1 < max_iter the samples still alive go to A.out. */
 template <typename T, int FRACTAL, int FPW_LOG2, bool EFFECTS>
 __global__ void __launch_bounds__(kBlockThreads)
-escape_kernel(const LaunchArgs A)
+tile_kernel(const LaunchArgs A)
 {
     constexpr int FPW = 1 << FPW_LOG2;
     constexpr int FPH = kWave / FPW;
+    constexpr int NF = RecFields<FRACTAL>::n;
 
     __shared__ LdsBlock S;
-    if (threadIdx.x == 0) {
-        S.pal = A.pal;
-        S.center_x = A.center_x; S.center_y = A.center_y; S.zoom = A.zoom;
-        S.julia_cx = A.julia_cx; S.julia_cy = A.julia_cy; S.log_bailout = A.log_bailout;
-        S.bailout = A.bailout; S.color_offset = A.color_offset; S.color_scale = A.color_scale;
-        S.trap_radius = A.trap_radius; S.stripe_density = A.stripe_density;
-        S.brightness = A.brightness; S.saturation = A.saturation; S.contrast = A.contrast;
-        S.max_iter = A.max_iter; S.W = A.W; S.H = A.H; S.aa = A.aa;
-    }
-    __syncthreads();
+    __shared__ WaveRing<T, NF> rings[EFFECTS ? 1 : kWavesPerBlock];
+    stage_constants(S, A);
 
     const int lane = threadIdx.x & (kWave - 1);
     const int lx = lane & (FPW - 1);
@@ -409,86 +659,38 @@ escape_kernel(const LaunchArgs A)
     const T inv_w = sizeof(T) == 8 ? (T)A.inv_w_d : (T)A.inv_w_f;
     const T inv_h = sizeof(T) == 8 ? (T)A.inv_h_d : (T)A.inv_h_f;
     const T aspect = sizeof(T) == 8 ? (T)A.aspect_d : (T)A.aspect_f;      /* shaders/julia.comp:221 */
-    const T inv_max_iter = (T)A.inv_max_iter;
-    const T inv_log2_bailout = (T)A.inv_log2_bailout;
     /* planes nobody asked for are not computed (wave-uniform branches) */
     const bool want_rgb = A.rgba != nullptr;
     const bool want_nu = want_rgb || A.nu != nullptr;
-    (void)inv_w; (void)aspect; (void)inv_log2_bailout;
+    const bool staged = !EFFECTS && A.i1 < max_iter;        /* survivors continue in the stream pass */
+    const int i1 = EFFECTS ? max_iter : A.i1;
+    (void)inv_w; (void)aspect; (void)H;
 
-    /* ---- persistent loop over the sharded tile queue ---- */
-    uint32_t shard = xcc_id();
-    uint32_t tried = 0;              /* shards found dry so far */
-    uint32_t seen = 0;               /* last head value observed on `shard` */
+    RingWriter<T, NF> writer;
+    writer.init(&rings[EFFECTS ? 0 : (threadIdx.x >> 6)], A.out, (uint32_t)lane);
 
-    /* Run length of one dequeue.  Two bounds:
-     *   guided  : remaining >> run_shift  -- longer runs first, run_min sub-tiles at the end of a shard;
-     *   paced   : (optional, pace_cycles > 0) pace_cycles / measured cycles per sub-tile of this wave's
-     *             previous run -- a wave in a cheap region claims many sub-tiles per atomic, a wave in the
-     *             set's interior one.  Only useful with the un-scattered order, where consecutive runs
-     *             of a shard are spatial neighbours; measured no better than short fixed runs on C2. */
-    const bool pacing = A.pace_cycles != 0;
-    uint32_t paced = pacing ? A.run_min : 0xFFFFFFFFu;      /* until the first run has been timed */
-    auto run_len = [&](uint32_t sh, uint32_t seen_head) -> uint32_t {
-        const uint32_t len = A.shard_len[sh];
-        const uint32_t rem = seen_head < len ? len - seen_head : 0u;
-        uint32_t n = rem >> A.run_shift;
-        n = n > paced ? paced : n;
-        n = n < A.run_min ? A.run_min : n;
-        return n > A.run_max ? A.run_max : n;
-    };
-    auto claim = [&](uint32_t sh, uint32_t n) -> uint32_t {
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&A.queue[sh * kShardStrideWords], n);
-        return v;
-    };
+    WaveQueue q;
+    q.init(A.q.heads, A.q.n_blk_padded, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max,
+           (A.q.flags & kQueuePrefetch) != 0, (uint32_t)lane);
 
-    const uint32_t wave_id = blockIdx.x * (kBlockThreads / kWave) + (threadIdx.x >> 6);
     uint64_t diag_t0 = 0;
-    uint32_t diag_subtiles = 0, diag_claims = 0;
+    uint32_t diag_items = 0, diag_claims = 0;
     if (A.diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
 
-    uint32_t cur_n = run_len(shard, seen);
-    uint32_t cur_raw = claim(shard, cur_n);
-
-    for (;;) {
-        uint32_t begin = __builtin_amdgcn_readfirstlane(cur_raw);
-        uint32_t count = cur_n;
-        const uint32_t cur_shard = shard;
-        const uint32_t len = A.shard_len[cur_shard];
+    uint32_t begin, count, cur_shard;
+    while (q.next(begin, count, cur_shard)) {
         ++diag_claims;
-        if (begin >= len) {
-            /* home shard dry: steal from the next one; exit after all 8 are dry */
-            if (++tried >= (uint32_t)kShards) break;
-            shard = (shard + 1u) & (uint32_t)(kShards - 1);
-            seen = 0;
-            cur_n = run_len(shard, seen);
-            cur_raw = claim(shard, cur_n);
-            continue;
-        }
-        if (begin + count > len) count = len - begin;
-        seen = begin + count;
-        /* prefetch: issue the next dequeue now; it is consumed after this run's arithmetic (hides
-         * the dequeue latency, but commits this wave to one more run) */
-        const bool prefetch = (A.queue_flags & kQueuePrefetch) != 0;
-        uint32_t next_n = 0, next_raw = 0;
-        if (prefetch) { next_n = run_len(shard, seen); next_raw = claim(shard, next_n); }
-        const uint64_t run_t0 = pacing ? __builtin_readcyclecounter() : 0ull;
-        diag_subtiles += count;
-
+        diag_items += count;
         for (uint32_t j = begin; j < begin + count; ++j) {
-            /* shard-local index -> global sub-tile id (blocks of kShardBlock dealt round-robin) */
-            /* ... and the dealt blocks are SCATTERED over the frame (bit-reversed block index): rows
-             * far from the set cost a few iterations per pixel and are bound by the dequeue latency,
-             * rows through it cost max_iter and are bound by VALU issue; scattering keeps both kinds
-             * in flight on every SIMD at all times instead of one phase after the other. */
+            /* shard-local index -> sub-tile id: blocks of kShardBlock sub-tiles dealt round-robin to
+             * the shards, optionally in bit-reversed (scattered) block order */
             const uint32_t dealt = (j / kShardBlock) * kShards + cur_shard;
-            const uint32_t blk = (A.queue_flags & kQueueScatter) ? __builtin_bitreverse32(dealt) >> A.blk_rev_shift : dealt;
-            if (blk >= A.n_blk) continue;
+            const uint32_t blk = (A.q.flags & kQueueScatter) ? __builtin_bitreverse32(dealt) >> A.q.blk_rev_shift : dealt;
+            if (blk >= A.q.n_blk) continue;
             const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
-            if (sid >= A.n_sub) continue;
-            const uint32_t sty = A.nsx_shift >= 0 ? sid >> A.nsx_shift : sid / A.nsx;
-            const uint32_t stx = sid - sty * A.nsx;
+            if (sid >= A.q.n_items) continue;
+            const uint32_t sty = A.q.nsx_shift >= 0 ? sid >> A.q.nsx_shift : sid / A.q.nsx;
+            const uint32_t stx = sid - sty * A.q.nsx;
             const int px = (int)stx * FPW + lx;
             const int lrow = (int)sty * FPH + ly;               /* row inside this part's packed rows */
             const bool inside = px < W && lrow < A.rows_local;
@@ -499,10 +701,12 @@ escape_kernel(const LaunchArgs A)
                 py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
             }
             const uint64_t outside_mask = __builtin_amdgcn_ballot_w64(!inside);
+            const uint32_t pixel = (uint32_t)lrow * (uint32_t)W + (uint32_t)px;
 
             float acc[3] = {0.0f, 0.0f, 0.0f};
             T first_nu = T(0);
             int first_it = 0;
+            bool alive = false;                                 /* staged: sample continues in the stream pass */
 
             const int nsamp = aa * aa;
             for (int s = 0; s < nsamp; ++s) {
@@ -533,24 +737,13 @@ escape_kernel(const LaunchArgs A)
                         /* |c| <= bailout for every live lane, else the first (tested) block
                          * retires the lane at i = 0 anyway; fast_ok also needs B^2 >= 4.5 */
                         T r2;
-                        escape_run<T>(o, B2, max_iter, A.fast_ok != 0, outside_mask, it, r2);
-                        if (want_nu) {
-                            nu = (T)it;                                       /* :172 */
-                            if (it < max_iter) {                              /* :173-177: mu = log2(log2|z|) */
-                                if (!A.lib_log) {
-                                    nu = (T)it + T(1) - log2_pos(T(0.5) * log2_pos(r2));
-                                } else {
-                                    const T log_zn = Real<T>::log(r2) / T(2);
-                                    nu = (T)it + T(1) - Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
-                                }
-                            }
+                        escape_run<T>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2);
+                        alive = staged && inside && it >= i1;
+                        if (staged) {
+                            const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
+                            writer.append(alive, pixel, rec);
                         }
-                        if (want_rgb) {
-                            T t = nu * inv_max_iter * (T)S.color_scale;       /* :179 */
-                            t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
-                            if (!(it >= max_iter && A.interior_style == 1))   /* :182-183, :190 */
-                                palette_eval(S.pal, pal_arg(t + (T)S.color_offset), rgb);
-                        }
+                        if (!alive) shade<T, 0>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
                     } else {
                         T zx = T(0), zy = T(0), ezx, ezy, min_trap;
                         escape_run_effects<T>(zx, zy, inside ? cx : T(0), inside ? cy : T(0), B2,
@@ -617,22 +810,13 @@ escape_kernel(const LaunchArgs A)
                     o.x2 = o.X * o.X;
                     o.y2d = o.Yd * o.Yd;
                     T r2;
-                    escape_run<T>(o, B2, max_iter, A.fast_ok != 0, outside_mask, it, r2);
-                    if (want_nu) {
-                        nu = (T)max_iter;                                     /* :243-244 interior: black */
-                        if (it < max_iter) {                                  /* :237-248 */
-                            /* log(log(r2)/log(B))/log 2 == log2(log2(r2) / log2(B)) */
-                            if (!A.lib_log)
-                                nu = (T)it + T(1) - log2_pos(log2_pos(r2) * inv_log2_bailout);
-                            else
-                                nu = (T)it + T(1) - Real<T>::log(Real<T>::log(r2) / (T)S.log_bailout) / Real<T>::ln2();
-                            if (want_rgb) {
-                                T t = nu * inv_max_iter;
-                                t = (T)S.color_offset + t * (T)S.color_scale;
-                                palette_eval(S.pal, pal_arg(t), rgb);
-                            }
-                        }
+                    escape_run<T>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2);
+                    alive = staged && inside && it >= i1;
+                    if (staged) {
+                        const T rec[NF] = {o.X, o.Yd};
+                        writer.append(alive, pixel, rec);
                     }
+                    if (!alive) shade<T, 1>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
                 }
                 if (s == 0) { first_nu = nu; first_it = it; }
                 acc[0] += rgb[0]; acc[1] += rgb[1]; acc[2] += rgb[2];
@@ -645,28 +829,119 @@ escape_kernel(const LaunchArgs A)
             if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                 post_chain(acc, S.brightness, S.saturation, S.contrast, FRACTAL == 1);
 
-            if (inside) {
-                const size_t o = (size_t)lrow * (size_t)W + (size_t)px;
-                if (A.rgba) A.rgba[o] = make_float4(acc[0], acc[1], acc[2], 1.0f);
-                if (A.nu) reinterpret_cast<T*>(A.nu)[o] = first_nu;
-                if (A.iter) A.iter[o] = first_it;
+            if (inside && !alive) {
+                if (A.rgba) A.rgba[pixel] = make_float4(acc[0], acc[1], acc[2], 1.0f);
+                if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = first_nu;
+                if (A.iter) A.iter[pixel] = first_it;
             }
         }
+    }
+    if (staged) writer.finish();
+    diag_write(A, (uint32_t)lane, diag_t0, diag_items, diag_claims);
+}
 
-        if (pacing) {   /* pace the claim after next from this run's measured cost (wave-uniform) */
-            const uint32_t dt = (uint32_t)(__builtin_readcyclecounter() - run_t0) | 1u;
-            const float want = (float)A.pace_cycles * (float)count * __builtin_amdgcn_rcpf((float)dt);
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)fminf(want, 1024.0f));
-            paced = n < 1u ? 1u : n;
+/* ---- stream pass ---------------------------------------------------------------------------------
+ * Continues the survivors of the previous pass over iterations [A.i0, A.i1): one record per lane,
+ * 64 live lanes per wave.  Finished samples are shaded and stored (scattered 16-byte stores, in
+ * tile order so neighbours share lines); samples alive at A.i1 < max_iter go to A.out. */
+template <typename T, int FRACTAL>
+__global__ void __launch_bounds__(kBlockThreads)
+stream_kernel(const LaunchArgs A)
+{
+    constexpr int NF = RecFields<FRACTAL>::n;
+    constexpr size_t kBlockBytes = RingWriter<T, NF>::kBlockBytes;
+
+    __shared__ LdsBlock S;
+    __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
+    stage_constants(S, A);
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const int max_iter = S.max_iter;
+    const T bailout = (T)S.bailout;
+    const T B2 = bailout * bailout;
+    const bool want_rgb = A.rgba != nullptr;
+    const bool want_nu = want_rgb || A.nu != nullptr;
+    const bool more = A.i1 < max_iter;
+
+    RingWriter<T, NF> writer;
+    writer.init(&rings[threadIdx.x >> 6], A.out, lane);
+
+    /* region k of the input stream is shard k of the queue; its length was written by the previous launch */
+    WaveQueue q;
+    q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max,
+                   (A.q.flags & kQueuePrefetch) != 0, lane);
+
+    uint64_t diag_t0 = 0;
+    uint32_t diag_items = 0, diag_claims = 0;
+    if (A.diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
+
+    struct Rec { uint32_t pixel; T X, Yd, cx, cyd; };
+    auto load = [&](uint32_t region, uint32_t blk) -> Rec {
+        const uint8_t* b = A.in.base + ((size_t)region * A.in.region_blocks + blk) * kBlockBytes;
+        const T* fields = reinterpret_cast<const T*>(b + 64 * 4);
+        Rec r;
+        r.pixel = reinterpret_cast<const uint32_t*>(b)[lane];
+        r.X = fields[lane];
+        r.Yd = fields[64 + lane];
+        if constexpr (FRACTAL == 0) { r.cx = fields[128 + lane]; r.cyd = fields[192 + lane]; }
+        else { r.cx = T(0); r.cyd = T(0); }
+        return r;
+    };
+
+    uint32_t begin, count, cur_shard;
+    while (q.next(begin, count, cur_shard)) {
+        ++diag_claims;
+        diag_items += count;
+        Rec cur = load(cur_shard, begin);
+        for (uint32_t j = begin; j < begin + count; ++j) {
+            /* the next block's records are requested before this block is iterated */
+            Rec nxt = cur;
+            if (j + 1 < begin + count) nxt = load(cur_shard, j + 1);
+            const uint32_t pixel = cur.pixel;
+            const bool valid = pixel != kInvalidPixel;
+            Orbit<T> o;
+            /* empty lanes of a partial block: z = 0, c = 0 */
+            o.X = valid ? cur.X : T(0);
+            o.Yd = valid ? cur.Yd : T(0);
+            if constexpr (FRACTAL == 0) {
+                o.cx = valid ? cur.cx : T(0);
+                o.cyd = valid ? cur.cyd : T(0);
+            } else {
+                o.cx = valid ? (T)S.julia_cx : T(0);
+                o.cyd = valid ? T(2) * (T)S.julia_cy : T(0);
+            }
+            o.x2 = o.X * o.X;
+            o.y2d = o.Yd * o.Yd;
+            int it;
+            T r2;
+            /* survivors got here without escaping for i0 >= 32 updates: start in unchecked blocks */
+            escape_run<T>(o, B2, A.i0, A.i1, A.fast_ok != 0, true,
+                          __builtin_amdgcn_ballot_w64(!valid), it, r2);
+            const bool alive = more && valid && it >= A.i1;
+            if (more) {
+                if constexpr (FRACTAL == 0) {
+                    const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
+                    writer.append(alive, pixel, rec);
+                } else {
+                    const T rec[NF] = {o.X, o.Yd};
+                    writer.append(alive, pixel, rec);
+                }
+            }
+            if (valid && !alive) {
+                T nu;
+                float rgb[3];
+                shade<T, FRACTAL>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
+                if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
+                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL == 1);
+                if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+                if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = nu;
+                if (A.iter) A.iter[pixel] = it;
+            }
+            cur = nxt;
         }
-        if (!prefetch) { next_n = run_len(shard, seen); next_raw = claim(shard, next_n); }
-        cur_raw = next_raw;
-        cur_n = next_n;
     }
-    if (A.diag && lane == 0) {      /* diagnostics: per-wave timeline (100 MHz ticks) and work counts */
-        uint64_t* d = A.diag + (size_t)wave_id * 4;
-        d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = diag_subtiles; d[3] = diag_claims;
-    }
+    if (more) writer.finish();
+    diag_write(A, lane, diag_t0, diag_items, diag_claims);
 }
 
 /* ---- 8-bit export: src/vk_engine.cpp:1344-1371 on the GPU ------------------------------------ */

@@ -83,15 +83,17 @@ class Renderer:
         _capi.check(self._lib.fr_ctx_set_option(self._ctx, name.encode(), int(value)))
 
     def set_tuning(self, workgroups_per_cu: int = 0, subtiles_per_dequeue: int = 0, shape: int = 0,
-                   run_min: int = 0, shift_bias: int = 0, pace_cycles: int = 0) -> None:
+                   run_min: int = 0, shift_bias: int = 0) -> None:
         """All queue knobs at once; 0 = automatic everywhere (see fr_ctx_set_option)."""
         for k, v in (("workgroups_per_cu", workgroups_per_cu), ("run_max", subtiles_per_dequeue),
-                     ("subtile_shape", shape), ("run_min", run_min), ("shift_bias", shift_bias),
-                     ("pace_cycles", pace_cycles)):
+                     ("subtile_shape", shape), ("run_min", run_min), ("shift_bias", shift_bias)):
             self.set_option(k, v)
 
     def last_grid(self) -> int:
-        return _capi.check(self._lib.fr_ctx_last_grid(self._ctx))
+        return _capi.check(self._lib.fr_ctx_last_grid(self._ctx)) & 0xFFFF
+
+    def last_stages(self) -> int:
+        return _capi.check(self._lib.fr_ctx_last_grid(self._ctx)) >> 16
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.fr_ctx_last_kernel_ms(self._ctx))

@@ -196,14 +196,22 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "workgroups_per_cu"  workgroups of 256 threads launched per compute unit
  *   "run_max", "run_min" longest / shortest run of sub-tiles one dequeue may claim
  *   "shift_bias"         signed change of log2 of the guided-run divisor
- *   "pace_cycles"        shader cycles of work a dequeue aims to claim (cost-paced run length)
+ *   "staging"            2 = staged (tile pass + survivor stream passes), 1 = single pass,
+ *                        0 = automatic (currently the single pass: faster on C2/C3/C4)
+ *   "stage_first"        iteration budget of the tile pass (default 32)
+ *   "stage_ratio"        budget growth per stream pass (default 4)
+ *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue may claim in a stream pass
+ *   "stream_workgroups_per_cu"          workgroups per compute unit of the stream pass
+ *   "queue_flags"        0x100 | 1 (bit-reversed tile order) | 2 (prefetch the next dequeue)
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1
  *   "diag_buffer"        device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks,
- *                        sub-tiles processed, dequeues); 0 disables
+ *                        items processed, dequeues); 0 disables.  "diag_stride" = uint64 words
+ *                        between the regions of consecutive stages
  * None of them can change a pixel (tests/test_gpu_parity.py::test_tuning_variants_are_bit_identical). */
 int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
 
-/* Workgroups launched by the most recent render on this context. */
+/* Workgroups per launch of the most recent render on this context (bits 0-15) and its number of
+ * stages (bits 16-..: 1 = single pass). */
 int fr_ctx_last_grid(fr_ctx* ctx);
 
 /* Number of compute units of the context's device (hipDeviceProp_t.multiProcessorCount). */

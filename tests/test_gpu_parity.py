@@ -159,18 +159,56 @@ def test_all_palettes(fr, renderer, oracle):
 
 
 def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
-    """Work-queue geometry must never change a pixel: every (workgroups/CU, run length, sub-tile shape)
-    gives byte-identical planes."""
+    """Work-queue geometry and the stage schedule must never change a pixel: every (workgroups/CU, run
+    length, sub-tile shape, staging on/off, first budget, budget ratio) gives byte-identical planes."""
     p, W, H = CASES["seahorse_0008_f64"]
     base = gpu_render(fr, renderer, p, 200, 120)
+    assert renderer.last_stages() == 1                     # the single pass is the default
+    opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "queue_flags", "stream_workgroups_per_cu")
     try:
         for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
             renderer.set_tuning(wg, run, shape)
             cur = gpu_render(fr, renderer, p, 200, 120)
             for a, b in zip(base, cur):
                 assert np.array_equal(a, b)
+        renderer.set_tuning()
+        for kw in (dict(staging=1), dict(staging=2), dict(staging=2, stage_first=16), dict(staging=2, stage_first=64, stage_ratio=2),
+                   dict(staging=2, stage_ratio=16), dict(staging=2, stage_first=512), dict(staging=2, stream_run_max=1),
+                   dict(queue_flags=0x100), dict(queue_flags=0x103), dict(staging=2, queue_flags=0x103),
+                   dict(staging=2, stage_first=16, stage_ratio=2, queue_flags=0x101, stream_workgroups_per_cu=2)):
+            for k, v in kw.items():
+                renderer.set_option(k, v)
+            cur = gpu_render(fr, renderer, p, 200, 120)
+            assert (renderer.last_stages() > 1) == (kw.get("staging") == 2)
+            for a, b in zip(base, cur):
+                assert np.array_equal(a, b), kw
+            for k in opts:
+                renderer.set_option(k, 0)
     finally:
         renderer.set_tuning()
+        for k in opts:
+            renderer.set_option(k, 0)
+
+
+@pytest.mark.parametrize("name", ["c3_julia_f32_centre0", "julia_f64_default_c", "c2_mandel_f32_mi1024",
+                                  "c4_seahorse_deep_f64", "mandel_small_bailout", "mandel_big_bailout",
+                                  "julia_c_outside_bailout", "mandel_scale_offset"])
+def test_staged_equals_single_pass(fr, renderer, oracle, name):
+    """Survivor compaction (tile pass + stream passes) against the single-pass kernel, bitwise, on a
+    frame large enough that rings wrap, blocks are partially filled and several stages run."""
+    p, _, _ = CASES[name]
+    W, H = 333, 207
+    single = gpu_render(fr, renderer, p, W, H)
+    assert renderer.last_stages() == 1
+    try:
+        renderer.set_option("staging", 2)
+        staged = gpu_render(fr, renderer, p, W, H)
+        n = renderer.last_stages()
+    finally:
+        renderer.set_option("staging", 0)
+    assert n > 1 or p.max_iterations < 64
+    for a, b in zip(staged, single):
+        assert np.array_equal(a, b)
 
 
 def test_export_rgb8(fr, renderer, oracle):
@@ -235,8 +273,14 @@ def test_c2_full_size_properties(fr, renderer, oracle):
         nu2 = torch.empty_like(nu); it2 = torch.empty_like(it); rgba2 = torch.empty_like(rgba)
         renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
         assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba)
+        renderer.set_tuning()
+        renderer.set_option("staging", 2)          # tile pass + survivor stream passes at full size
+        renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
+        assert renderer.last_stages() == 4
+        assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba)
     finally:
         renderer.set_tuning()
+        renderer.set_option("staging", 0)
     tot_it, tot_nu = 0, 0.0
     for part in range(8):
         sh = fr.Shard(part, 8, 32)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of one render from the kernel's diag buffer: when waves start/finish, how the
-work and the dequeues are spread.  usage: timeline.py workload [max_iter] [opt=value ...]"""
+"""Per-wave timeline of one render from the kernels' diag buffer, per stage: when waves start/finish,
+how the work and the dequeues are spread.  usage: timeline.py workload [max_iter] [opt=value ...]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,30 +16,33 @@ if args and args[0].isdigit():
 W, H = w["W"], w["H"]
 r = fr.Renderer(0)
 for a in args:
-    k, v = a.split("="); r.set_option(k, int(v))
+    k, v = a.split("="); r.set_option(k, int(v, 0))
 rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
 kw = dict(fractal_type=fr.FractalType[w["fractal"]], precision=fr.Precision[w["precision"]], rgba=rgba)
 state = fr.FractalState(**st)
-r.render(state, W, H, **kw)
-nw = r.last_grid() * 4
-diag = torch.zeros((nw, 4), dtype=torch.int64, device="cuda:0")
+for _ in range(3):
+    r.render(state, W, H, **kw)
+base_ms = r.last_kernel_ms()
+nw = r.compute_units * 8 * 4
+nst = r.last_stages()
+diag = torch.zeros((nst, nw, 4), dtype=torch.int64, device="cuda:0")
+r.set_option("diag_stride", nw * 4)
 r.set_option("diag_buffer", diag.data_ptr())
-r.render(state, W, H, **kw); ms = r.last_kernel_ms()
-r.render(state, W, H, **kw); ms = r.last_kernel_ms()
+for _ in range(3):
+    r.render(state, W, H, **kw)
+ms = r.last_kernel_ms()
 d = diag.cpu().numpy()
-ran = d[:, 1] > 0
-t0 = d[ran, 0].min()
-start = (d[ran, 0] - t0) / 100.0   # us (100 MHz ticks)
-end = (d[ran, 1] - t0) / 100.0
-sub, claims = d[ran, 2], d[ran, 3]
-span = end.max()
-print(f"{sys.argv[1]} {st}: kernel {ms:.4f} ms, grid {nw//4} WG, waves that ran {ran.sum()}/{nw}, span {span:.1f} us")
-print("  wave start  us  p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(start, [50, 90, 99, 100])))
-print("  wave finish us  p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(end, [1, 10, 50, 90, 99, 100])))
-worked = sub > 0
-print(f"  waves with work {worked.sum()}, sub-tiles/wave mean {sub[worked].mean():.1f} min {sub[worked].min()} max {sub[worked].max()}, "
-      f"dequeues total {claims.sum()} (mean/wave {claims.mean():.1f}), sub-tiles/dequeue {sub.sum()/max(1,claims.sum()-8*ran.sum()):.2f}")
-# how much SIMD-time is idle at the end: integrate number of live waves over time
-edges = np.linspace(0, span, 41)
-live = [(np.minimum(end, b) - np.maximum(start, a)).clip(min=0).sum() / (b - a) for a, b in zip(edges[:-1], edges[1:])]
-print("  live waves per 2.5% time slice:", " ".join(f"{x:.0f}" for x in live))
+t0 = d[d[:, :, 1] > 0][:, 0].min()
+print(f"{sys.argv[1]} {st} {' '.join(args)}: kernel {base_ms:.4f} ms ({ms:.4f} with diag), {nst} stage(s), grid {r.last_grid()} WG")
+for s in range(nst):
+    ds = d[s]; ran = ds[:, 1] > 0
+    if not ran.any():
+        print(f"  stage {s}: no waves"); continue
+    start = (ds[ran, 0] - t0) / 100.0; end = (ds[ran, 1] - t0) / 100.0
+    items, claims = ds[ran, 2], ds[ran, 3]
+    lo, hi = start.min(), end.max()
+    edges = np.linspace(lo, hi, 11)
+    live = [(np.minimum(end, b) - np.maximum(start, a)).clip(min=0).sum() / max(b - a, 1e-9) for a, b in zip(edges[:-1], edges[1:])]
+    worked = items > 0
+    print(f"  stage {s}: {lo:8.1f} -> {hi:8.1f} us ({hi-lo:7.1f}), waves {ran.sum()} ({worked.sum()} with work), items/wave mean {items[worked].mean() if worked.any() else 0:.1f} "
+          f"max {items.max()}, dequeues {claims.sum()}, finish p50 {np.percentile(end,50)-lo:.1f} p99 {np.percentile(end,99)-lo:.1f}; live/10%: " + " ".join(f"{x:.0f}" for x in live))
