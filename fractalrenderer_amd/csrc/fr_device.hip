@@ -31,6 +31,10 @@ struct fr_ctx {
     uint32_t* d_ctrl;           /* queue heads + stream counters of every stage (kCtrlWords) */
     void* stream_buf[2];        /* ping-pong survivor streams */
     size_t stream_bytes;
+    uint32_t tune_pool;         /* 0 = automatic (currently off), 1 = off, 2 = on: lane-pool kernel */
+    uint32_t tune_pool_refill;  /* idle lanes that trigger a refill (0 = 32) */
+    uint32_t tune_pool_evict;   /* stream pool: running lanes at or below which a dry wave evicts (0 = 32) */
+    uint32_t tune_pool_passes;  /* stream pool passes (0 = 1) */
     uint32_t tune_staging;      /* 0 = automatic (currently off), 1 = off (single pass), 2 = on */
     uint32_t tune_stage_first;  /* first budget b0 (0 = 32) */
     uint32_t tune_stage_ratio;  /* budget growth per stage (0 = 4) */
@@ -130,8 +134,20 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         if (value != 0 && value != 3 && value != 4 && value != 6)
             return fr_set_error(FR_ERR_INVALID_ARG, "subtile_shape must be 0, 3 (8x8), 4 (16x4) or 6 (64x1)");
         c->tune_shape = (uint32_t)value;
+    } else if (!strcmp(name, "pool")) {
+        if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "pool must be 0 (automatic), 1 (off) or 2 (on)");
+        c->tune_pool = (uint32_t)value;
+    } else if (!strcmp(name, "pool_refill_at")) {
+        if (value < 0 || value > 64) return fr_set_error(FR_ERR_INVALID_ARG, "pool_refill_at must be in [0,64]");
+        c->tune_pool_refill = (uint32_t)value;
+    } else if (!strcmp(name, "pool_evict_at")) {
+        if (value < 0 || value > 64) return fr_set_error(FR_ERR_INVALID_ARG, "pool_evict_at must be in [0,64]");
+        c->tune_pool_evict = (uint32_t)value;
+    } else if (!strcmp(name, "pool_passes")) {
+        if (value < 0 || value > 8) return fr_set_error(FR_ERR_INVALID_ARG, "pool_passes must be in [0,8]");
+        c->tune_pool_passes = (uint32_t)value;
     } else if (!strcmp(name, "staging")) {
-        if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "staging must be 0 (automatic), 1 (off) or 2 (on)");
+        if (value < 0 || value > 3) return fr_set_error(FR_ERR_INVALID_ARG, "staging must be 0 (automatic), 1 (off), 2 (block stages) or 3 (tile pass + lane-pool pass)");
         c->tune_staging = (uint32_t)value;
     } else if (!strcmp(name, "stage_first")) {
         if (value < 0 || value > (1 << 24)) return fr_set_error(FR_ERR_INVALID_ARG, "stage_first out of range");
@@ -229,6 +245,24 @@ static hipError_t launch_tile(int shape, dim3 grid, hipStream_t s, const LaunchA
 }
 
 template <typename T, int FRACTAL>
+static hipError_t launch_pool(int shape, dim3 grid, hipStream_t s, const LaunchArgs& a)
+{
+    switch (shape) {
+    case 6: hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 6, false>), grid, dim3(kBlockThreads), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 4, false>), grid, dim3(kBlockThreads), 0, s, a); break;
+    default: hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, false>), grid, dim3(kBlockThreads), 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+template <typename T, int FRACTAL>
+static hipError_t launch_stream_pool(dim3 grid, hipStream_t s, const LaunchArgs& a)
+{
+    hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, true>), grid, dim3(kBlockThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+template <typename T, int FRACTAL>
 static hipError_t launch_stream(dim3 grid, hipStream_t s, const LaunchArgs& a)
 {
     hipLaunchKernelGGL((stream_kernel<T, FRACTAL>), grid, dim3(kBlockThreads), 0, s, a);
@@ -314,21 +348,37 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     int bounds[kMaxStages];
     int nstage = 0;
     {
-        /* measured (profiles/r01_staging_sweeps.txt): the single pass is faster on C2/C3/C4, staging wins
-         * only on C5 (+9 %); it stays opt-in ("staging" = 2) until the per-stage tails are gone */
-        const bool allow = !effects && p->antialiasing_samples <= 1 && c->tune_staging == 2;
-        const int first = c->tune_stage_first ? (int)c->tune_stage_first : 32;
+        /* automatic = tile pass + one lane-pool pass (staging 3): measured faster than the single pass on
+         * C2 (+5 %), C3 (+30 %), C5 (+40 %), 1 % slower on C4 (profiles/r01_staging_sweeps.txt) */
+        const uint32_t mode = c->tune_staging ? c->tune_staging : 3u;
+        const bool allow = !effects && p->antialiasing_samples <= 1 && (mode == 2 || mode == 3);
+        /* tile-pass budget: ~max_iter/48 rounded to the unchecked block, within [32, 128] (measured best:
+         * 32 at max_iter 1024, 48 at 2048, 96-128 at 4096) */
+        int auto_first = ((max_iter / 48 + kFastBlock / 2) / kFastBlock) * kFastBlock;
+        auto_first = auto_first < 32 ? 32 : (auto_first > 128 ? 128 : auto_first);
+        const int first = c->tune_stage_first ? (int)c->tune_stage_first : auto_first;
         const int ratio = c->tune_stage_ratio >= 2 ? (int)c->tune_stage_ratio : 4;
         if (allow && max_iter >= 2 * first) {
             long long b = first - first % kFastBlock;            /* budgets are multiples of the unchecked block */
             if (b < kFastBlock) b = kFastBlock;
-            while (b < max_iter && nstage < kMaxStages - 1) { bounds[nstage++] = (int)b; b *= ratio; }
+            while (b < max_iter && nstage < kMaxStages - 1) {
+                bounds[nstage++] = (int)b;
+                b *= ratio;
+                if (mode == 3) break;                            /* tile pass + lane-pool passes to max_iter */
+            }
             /* do not leave a last stage much shorter than the one before it */
             if (nstage >= 2 && max_iter - bounds[nstage - 1] < bounds[nstage - 1] / 4) --nstage;
         }
         bounds[nstage++] = max_iter;
+        if (nstage > 1 && mode == 3) {
+            /* lane-pool passes all run to max_iter; each hands the lanes it would have to run out alone
+             * (queue dry, few lanes left per wave) to the next, much smaller pass; the last runs out */
+            const int extra = c->tune_pool_passes ? (int)c->tune_pool_passes - 1 : 0;   /* measured: follow-up passes cost more than they save */
+            for (int k = 0; k < extra && nstage < kMaxStages; ++k) bounds[nstage++] = max_iter;
+        }
     }
     const bool staged = nstage > 1;
+    const bool pool_stream = staged && (c->tune_staging ? c->tune_staging : 3u) == 3u;
 
     /* ---- geometry of the tile pass -------------------------------------------------------------- */
     const int shape = c->tune_shape ? (int)c->tune_shape : 3;
@@ -374,12 +424,13 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         tq.run_min = c->tune_run_min ? c->tune_run_min : 2u;
     }
     if (tq.run_min > tq.run_max) tq.run_min = tq.run_max;
-    tq.flags = c->tune_queue_flags ? (c->tune_queue_flags & 0xFFu) : kQueuePrefetch;
+    /* no claim-ahead by default: measured equal or better without it on every workload */
+    tq.flags = c->tune_queue_flags ? (c->tune_queue_flags & 0xFFu) : 0u;
     c->last_grid = grid;
 
     /* ---- survivor streams (ping-pong) in context scratch ------------------------------------------ */
     const size_t nfields = julia ? 2 : 4;
-    const size_t block_bytes = 64 * 4 + nfields * 64 * (f64 ? 8 : 4);
+    const size_t block_bytes = 2 * 64 * 4 + nfields * 64 * (f64 ? 8 : 4);
     /* the stream kernel holds 6 workgroups per CU (57 VGPRs, SGPR-limited); its blocks are latency
      * bound (dequeue -> record loads -> iterate -> scattered stores), so run all of them */
     const uint32_t sgrid = (uint32_t)c->compute_units * (c->tune_stream_wg_per_cu ? c->tune_stream_wg_per_cu : 6u);
@@ -418,7 +469,18 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     }
     a.diag = c->diag;
     hipError_t e;
-    if (julia) {
+    const bool pool = !staged && !effects && p->antialiasing_samples <= 1 && c->tune_pool == 2;
+    if (pool) {
+        /* lane pool: claims are rare (a run of sub-tiles feeds 64 lanes for many refills) */
+        a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 32u;
+        if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
+        a.q.run_min = c->tune_run_min ? c->tune_run_min : 4u;
+        a.q.run_max = c->tune_run_max ? c->tune_run_max : 16u;
+        if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
+        a.q.run_shift = clamp_shift((int)ceil_log2(4u * waves_per_shard));
+        if (julia) e = f64 ? launch_pool<double, 1>(shape, dim3(grid), stream, a) : launch_pool<float, 1>(shape, dim3(grid), stream, a);
+        else       e = f64 ? launch_pool<double, 0>(shape, dim3(grid), stream, a) : launch_pool<float, 0>(shape, dim3(grid), stream, a);
+    } else if (julia) {
         e = f64 ? launch_tile<double, 1, false>(shape, dim3(grid), stream, a)
                 : launch_tile<float, 1, false>(shape, dim3(grid), stream, a);
     } else if (effects) {
@@ -450,7 +512,28 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
         a.q.flags = tq.flags & kQueuePrefetch;
         a.diag = c->diag ? c->diag + (size_t)k * c->diag_stride : nullptr;
-        if (julia) e = f64 ? launch_stream<double, 1>(dim3(sgrid), stream, a) : launch_stream<float, 1>(dim3(sgrid), stream, a);
+        if (pool_stream) {
+            a.i0 = bounds[0];
+            a.i1 = max_iter;
+            a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
+            if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
+            a.pool_evict_at = c->tune_pool_evict ? c->tune_pool_evict : 32u;
+            if (k == nstage - 1) { a.out.base = nullptr; a.pool_evict_at = 0; }      /* last pass runs everything out */
+            /* a lane-pool wave holds its claimed blocks as a private reserve and only stalls for a dequeue
+             * once per reserve, so claim little and never ahead: what a wave has reserved when the queue
+             * runs dry is exactly the tail of the pass (measured: 1-3 block runs + one run prefetched left
+             * a 315 us drain on C2; a block of 64 interior records is ~60 us of work at 5 waves/SIMD) */
+            a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 1u;
+            a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 2u;
+            a.q.flags &= ~kQueuePrefetch;
+            if (k >= 2) {
+                /* follow-up passes read the partial blocks evicted by the previous pass (a few lanes per
+                 * block): claim several per dequeue so that the records fill whole waves */
+                a.q.run_min = 4u; a.q.run_max = 8u;
+            }
+            if (julia) e = f64 ? launch_stream_pool<double, 1>(dim3(sgrid), stream, a) : launch_stream_pool<float, 1>(dim3(sgrid), stream, a);
+            else       e = f64 ? launch_stream_pool<double, 0>(dim3(sgrid), stream, a) : launch_stream_pool<float, 0>(dim3(sgrid), stream, a);
+        } else if (julia) e = f64 ? launch_stream<double, 1>(dim3(sgrid), stream, a) : launch_stream<float, 1>(dim3(sgrid), stream, a);
         else       e = f64 ? launch_stream<double, 0>(dim3(sgrid), stream, a) : launch_stream<float, 0>(dim3(sgrid), stream, a);
         if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "stream kernel launch failed: %s", hipGetErrorString(e));
     }

@@ -56,8 +56,8 @@ constexpr uint32_t kInvalidPixel = 0xFFFFFFFFu;
 constexpr int kRingSlots = 128;          /* survivor ring capacity per wave (records)      */
 
 /* One survivor stream in device scratch: blocks of 64 records, each block laid out
- * [pixel u32 x64][X x64][Yd x64]([cx x64][cyd x64] for Mandelbrot), so every field is one
- * coalesced access per wave. */
+ * [pixel u32 x64][iterations done u32 x64][X x64][Yd x64]([cx x64][cyd x64] for Mandelbrot), so
+ * every field is one coalesced access per wave. */
 struct StreamRef {
     uint8_t* base;               /* kShards regions of region_blocks blocks each */
     uint32_t* n_blocks;          /* kShards device counters, kShardStrideWords apart: blocks appended per region */
@@ -112,6 +112,8 @@ struct LaunchArgs {
     /* stage: this launch runs iterations [i0, i1); i1 < max_iter -> unfinished pixels go to `out` */
     int32_t i0, i1;
     StreamRef in, out;
+    uint32_t pool_refill_at;     /* lane pool: finished lanes wait until this many are idle */
+    uint32_t pool_evict_at;      /* lane pool over a stream: queue dry and <= this many lanes running -> hand them to `out` */
     /* outputs */
     float4* rgba;
     void* nu;
@@ -391,15 +393,25 @@ struct WaveQueue {
     __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& count, uint32_t& sh)
     {
         if (pending) { cur_n = next_n; cur_raw = next_raw; }
-        else { cur_n = run_len(shard, seen); cur_raw = claim(shard, cur_n); }
+        else {
+            /* shards known to be empty cost no atomic (a follow-up pass may have nothing to do) */
+            while (shard_len(shard) == 0u) {
+                if (++tried >= (uint32_t)kShards) return false;
+                shard = (shard + 1u) & (uint32_t)(kShards - 1);
+                seen = 0;
+            }
+            cur_n = run_len(shard, seen); cur_raw = claim(shard, cur_n);
+        }
         pending = false;
         started = true;
         for (;;) {
             const uint32_t b = __builtin_amdgcn_readfirstlane(cur_raw);
             const uint32_t l = shard_len(shard);
             if (b >= l) {
-                if (++tried >= (uint32_t)kShards) return false;
-                shard = (shard + 1u) & (uint32_t)(kShards - 1);
+                do {
+                    if (++tried >= (uint32_t)kShards) return false;
+                    shard = (shard + 1u) & (uint32_t)(kShards - 1);
+                } while (shard_len(shard) == 0u);
                 seen = 0;
                 cur_n = run_len(shard, seen);
                 cur_raw = claim(shard, cur_n);
@@ -423,6 +435,7 @@ struct WaveQueue {
 template <typename T, int NF>
 struct WaveRing {
     uint32_t pix[kRingSlots];
+    uint32_t it[kRingSlots];
     T f[NF][kRingSlots];
 };
 
@@ -434,7 +447,8 @@ struct RingWriter {
     uint32_t head, tail;          /* wave-uniform record counters */
     uint32_t home;                /* region this wave appends to (its XCD) */
 
-    static constexpr size_t kBlockBytes = 64 * 4 + (size_t)NF * 64 * sizeof(T);
+    static constexpr size_t kHeaderBytes = 2 * 64 * 4;           /* pixel + iterations-done planes */
+    static constexpr size_t kBlockBytes = kHeaderBytes + (size_t)NF * 64 * sizeof(T);
 
     __device__ __forceinline__ void init(WaveRing<T, NF>* r, const StreamRef& o, uint32_t ln)
     {
@@ -461,13 +475,14 @@ struct RingWriter {
         const bool valid = lane < nvalid;
         uint8_t* b = out.base + ((size_t)region * out.region_blocks + blk) * kBlockBytes;
         reinterpret_cast<uint32_t*>(b)[lane] = valid ? ring->pix[slot] : kInvalidPixel;
-        T* fields = reinterpret_cast<T*>(b + 64 * 4);
+        reinterpret_cast<uint32_t*>(b)[64 + lane] = valid ? ring->it[slot] : 0u;
+        T* fields = reinterpret_cast<T*>(b + kHeaderBytes);
 #pragma unroll
         for (int k = 0; k < NF; ++k) fields[k * 64 + lane] = valid ? ring->f[k][slot] : T(0);
         head += nvalid;
     }
-    /* append the lanes with `keep` set; v[] are the record fields */
-    __device__ __forceinline__ void append(bool keep, uint32_t pixel, const T (&v)[NF])
+    /* append the lanes with `keep` set; `done` = iterations the sample has run, v[] the record fields */
+    __device__ __forceinline__ void append(bool keep, uint32_t pixel, uint32_t done, const T (&v)[NF])
     {
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
         if (m == 0ull) return;
@@ -476,6 +491,7 @@ struct RingWriter {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             const uint32_t slot = (tail + rank) & (kRingSlots - 1);
             ring->pix[slot] = pixel;
+            ring->it[slot] = done;
 #pragma unroll
             for (int k = 0; k < NF; ++k) ring->f[k][slot] = v[k];
         }
@@ -741,7 +757,7 @@ tile_kernel(const LaunchArgs A)
                         alive = staged && inside && it >= i1;
                         if (staged) {
                             const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
-                            writer.append(alive, pixel, rec);
+                            writer.append(alive, pixel, (uint32_t)i1, rec);
                         }
                         if (!alive) shade<T, 0>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
                     } else {
@@ -814,7 +830,7 @@ tile_kernel(const LaunchArgs A)
                     alive = staged && inside && it >= i1;
                     if (staged) {
                         const T rec[NF] = {o.X, o.Yd};
-                        writer.append(alive, pixel, rec);
+                        writer.append(alive, pixel, (uint32_t)i1, rec);
                     }
                     if (!alive) shade<T, 1>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
                 }
@@ -878,7 +894,7 @@ stream_kernel(const LaunchArgs A)
     struct Rec { uint32_t pixel; T X, Yd, cx, cyd; };
     auto load = [&](uint32_t region, uint32_t blk) -> Rec {
         const uint8_t* b = A.in.base + ((size_t)region * A.in.region_blocks + blk) * kBlockBytes;
-        const T* fields = reinterpret_cast<const T*>(b + 64 * 4);
+        const T* fields = reinterpret_cast<const T*>(b + RingWriter<T, NF>::kHeaderBytes);
         Rec r;
         r.pixel = reinterpret_cast<const uint32_t*>(b)[lane];
         r.X = fields[lane];
@@ -921,10 +937,10 @@ stream_kernel(const LaunchArgs A)
             if (more) {
                 if constexpr (FRACTAL == 0) {
                     const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
-                    writer.append(alive, pixel, rec);
+                    writer.append(alive, pixel, (uint32_t)A.i1, rec);
                 } else {
                     const T rec[NF] = {o.X, o.Yd};
-                    writer.append(alive, pixel, rec);
+                    writer.append(alive, pixel, (uint32_t)A.i1, rec);
                 }
             }
             if (valid && !alive) {
@@ -941,6 +957,281 @@ stream_kernel(const LaunchArgs A)
         }
     }
     if (more) writer.finish();
+    diag_write(A, lane, diag_t0, diag_items, diag_claims);
+}
+
+/* ---- lane pool ------------------------------------------------------------------------------------
+ * Persistent LANES: a lane that finishes its pixel is refilled with the next pixel of the wave's
+ * reserve (pixels in tile order, claimed a run of sub-tiles at a time from the XCD-sharded queue),
+ * so a wave stays full whatever the spread of escape times (a 64-pixel tile of a Julia dust runs
+ * 25 % full when it must wait for its slowest lane) and the frame balances at pixel granularity.
+ *
+ *   - wclock: iterations this wave has run (wave-uniform, SGPR).  A lane refilled at wclock = s has
+ *     deadline = s + max_iter; it escapes with index  wclock - s  or is interior when wclock
+ *     reaches its deadline.  The earliest deadline is kept wave-uniform, so reaching it costs one
+ *     scalar compare per iteration and nothing per lane.
+ *   - unchecked blocks of 16 updates stay legal at ANY alignment: if the block is clean (no lane
+ *     escaped in all 16 updates) then a lane whose deadline fell inside the block did not escape
+ *     before its deadline either -> interior, exactly.  A dirty block is rolled back and replayed
+ *     tested, where deadlines are honoured to the iteration.
+ *   - finished lanes wait (parked at z = 0, c = 0) until `refill_at` lanes are idle, then they are
+ *     shaded, stored (16-byte scattered stores; neighbours in tile order finish close in time and
+ *     merge in L2) and refilled together, so the per-pixel code runs reasonably full.
+ * Results are bit-identical to the tile pass: same per-lane operation sequence. */
+template <typename T>
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+/* FROM_STREAM = false: lanes are refilled with fresh pixels (coordinates from the pixel index);
+ * FROM_STREAM = true : lanes are refilled with survivor records of the tile pass (A.in), and run the
+ *                      remaining iterations [A.i0, max_iter). */
+template <typename T, int FRACTAL, int FPW_LOG2, bool FROM_STREAM>
+__global__ void __launch_bounds__(kBlockThreads)
+pool_kernel(const LaunchArgs A)
+{
+    constexpr int FPW = 1 << FPW_LOG2;
+    constexpr int FPH = kWave / FPW;
+    constexpr int NF = RecFields<FRACTAL>::n;
+    constexpr size_t kBlockBytes = RingWriter<T, NF>::kBlockBytes;
+
+    __shared__ LdsBlock S;
+    __shared__ WaveRing<T, NF> rings[FROM_STREAM ? kWavesPerBlock : 1];
+    stage_constants(S, A);
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const int W = S.W, H = S.H, max_iter = S.max_iter;
+    const T center_x = (T)S.center_x, center_y = (T)S.center_y, zoom = (T)S.zoom;
+    const T bailout = (T)S.bailout;
+    const T B2 = bailout * bailout;
+    const T resx = (T)W, resy = (T)H;
+    const T inv_w = sizeof(T) == 8 ? (T)A.inv_w_d : (T)A.inv_w_f;
+    const T inv_h = sizeof(T) == 8 ? (T)A.inv_h_d : (T)A.inv_h_f;
+    const T aspect = sizeof(T) == 8 ? (T)A.aspect_d : (T)A.aspect_f;
+    const bool want_rgb = A.rgba != nullptr;
+    const bool want_nu = want_rgb || A.nu != nullptr;
+    const bool fast_ok = A.fast_ok != 0;
+    const uint32_t refill_at = A.pool_refill_at;
+    /* a wave left with at most this many running lanes once the queue is dry hands them to A.out
+     * (the next, much smaller pool pass packs such leftovers into full waves) instead of running
+     * them out alone */
+    const uint32_t evict_at = (FROM_STREAM && A.out.base) ? A.pool_evict_at : 0u;
+    (void)inv_w; (void)aspect; (void)H; (void)W; (void)center_x; (void)center_y; (void)zoom; (void)resx; (void)resy; (void)inv_h;
+
+    RingWriter<T, NF> writer;
+    writer.init(&rings[FROM_STREAM ? (threadIdx.x >> 6) : 0], A.out, lane);
+
+    WaveQueue q;
+    if constexpr (FROM_STREAM)
+        q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max,
+                       (A.q.flags & kQueuePrefetch) != 0, lane);
+    else
+        q.init(A.q.heads, A.q.n_blk_padded, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max,
+               (A.q.flags & kQueuePrefetch) != 0, lane);
+
+    uint64_t diag_t0 = 0;
+    uint32_t diag_items = 0, diag_claims = 0;
+    if (A.diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
+
+    /* per-lane state */
+    uint32_t pixel = kInvalidPixel;      /* kInvalidPixel: lane is free */
+    bool fin = false;                    /* finished, waiting to be shaded and stored */
+    Orbit<T> o;
+    o.X = o.Yd = o.cx = o.cyd = o.x2 = o.y2d = T(0);
+    uint32_t deadline = 0;
+    int esc_i = 0;
+    T esc_r2 = T(0);
+    /* wave-uniform state */
+    uint32_t wclock = 0;
+    uint32_t next_deadline = 0;          /* a lower bound of the earliest deadline among running lanes */
+    bool have_running = false;
+    uint32_t res_begin = 0, res_count = 0, res_shard = 0, res_next = 0;    /* reserve: run of 64-item groups, cursor in items */
+    bool dry = false, fast = false;
+
+    for (;;) {
+        /* ---- retire: shade and store the finished lanes ---- */
+        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
+            if (fin) {
+                T nu;
+                float rgb[3];
+                shade<T, FRACTAL>(A, S, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
+                if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
+                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL == 1);
+                if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+                if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = nu;
+                if (A.iter) A.iter[pixel] = esc_i;
+                pixel = kInvalidPixel;
+                fin = false;
+            }
+        }
+        /* ---- refill the free lanes from the reserve ---- */
+        for (;;) {
+            const uint64_t freem = __builtin_amdgcn_ballot_w64(pixel == kInvalidPixel);
+            if (freem == 0ull || dry) break;
+            if (res_next == res_count * 64u) {
+                if (!q.next(res_begin, res_count, res_shard)) { dry = true; break; }
+                res_next = 0;
+                ++diag_claims;
+                diag_items += res_count;
+            }
+            const uint32_t nfree = (uint32_t)__builtin_popcountll(freem);
+            const uint32_t avail = res_count * 64u - res_next;
+            const uint32_t n = nfree < avail ? nfree : avail;
+            if (pixel == kInvalidPixel) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freem, 0u));
+                if (rank < n) {
+                    const uint32_t t = res_next + rank;
+                    const uint32_t j = res_begin + (t >> 6), l = t & 63u;
+                    if constexpr (FROM_STREAM) {
+                        /* record l of block j of region res_shard */
+                        const uint8_t* b = A.in.base + ((size_t)res_shard * A.in.region_blocks + j) * kBlockBytes;
+                        const T* fields = reinterpret_cast<const T*>(b + RingWriter<T, NF>::kHeaderBytes);
+                        const uint32_t pix = reinterpret_cast<const uint32_t*>(b)[l];
+                        if (pix != kInvalidPixel) {
+                            pixel = pix;
+                            const uint32_t done = reinterpret_cast<const uint32_t*>(b)[64 + l];
+                            o.X = fields[l];
+                            o.Yd = fields[64 + l];
+                            if constexpr (FRACTAL == 0) { o.cx = fields[128 + l]; o.cyd = fields[192 + l]; }
+                            else { o.cx = (T)S.julia_cx; o.cyd = T(2) * (T)S.julia_cy; }
+                            o.x2 = o.X * o.X;
+                            o.y2d = o.Yd * o.Yd;
+                            deadline = wclock + ((uint32_t)max_iter - done);
+                        }
+                    } else {
+                        /* pixel l of sub-tile j (shard-local index) */
+                        const uint32_t dealt = (j / kShardBlock) * kShards + res_shard;
+                        const uint32_t blk = (A.q.flags & kQueueScatter) ? __builtin_bitreverse32(dealt) >> A.q.blk_rev_shift : dealt;
+                        const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
+                        const uint32_t sty = A.q.nsx_shift >= 0 ? sid >> A.q.nsx_shift : sid / A.q.nsx;
+                        const uint32_t stx = sid - sty * A.q.nsx;
+                        const int px = (int)stx * FPW + (int)(l & (FPW - 1));
+                        const int lrow = (int)sty * FPH + (int)(l >> FPW_LOG2);
+                        const bool inside = blk < A.q.n_blk && sid < A.q.n_items && px < W && lrow < A.rows_local;
+                        if (inside) {
+                            int py = lrow;
+                            if (A.nparts != 1) {
+                                const int strip = lrow / A.rows_per_strip;
+                                py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
+                            }
+                            pixel = (uint32_t)lrow * (uint32_t)W + (uint32_t)px;
+                            deadline = wclock + (uint32_t)max_iter;
+                            if constexpr (FRACTAL == 0) {
+                                T uvx, uvy;                       /* shaders/mandelbrot.comp:149-151 */
+                                if (A.exact_div_ok) {
+                                    uvx = div_by<T>((T)px - T(0.5) * resx, resy, inv_h);
+                                    uvy = div_by<T>((T)py - T(0.5) * resy, resy, inv_h);
+                                } else {
+                                    uvx = ((T)px - T(0.5) * resx) / resy;
+                                    uvy = ((T)py - T(0.5) * resy) / resy;
+                                }
+                                o.X = T(0); o.Yd = T(0); o.x2 = T(0); o.y2d = T(0);
+                                o.cx = center_x + uvx * zoom;
+                                o.cyd = T(2) * (center_y + uvy * zoom);
+                            } else {
+                                T uvx, uvy;                       /* shaders/julia.comp:325, :221-225 */
+                                if (A.exact_div_ok) {
+                                    uvx = div_by<T>((T)px, resx, inv_w);
+                                    uvy = div_by<T>((T)py, resy, inv_h);
+                                } else {
+                                    uvx = (T)px / resx; uvy = (T)py / resy;
+                                }
+                                o.X = center_x + (uvx - T(0.5)) * zoom * aspect;
+                                o.Yd = T(2) * (center_y + (uvy - T(0.5)) * zoom);
+                                o.cx = (T)S.julia_cx;
+                                o.cyd = T(2) * (T)S.julia_cy;
+                                o.x2 = o.X * o.X;
+                                o.y2d = o.Yd * o.Yd;
+                            }
+                        }
+                    }
+                }
+            }
+            res_next += n;
+        }
+        const uint64_t active = __builtin_amdgcn_ballot_w64(pixel != kInvalidPixel);
+        if (active == 0ull) break;                           /* queue dry and every lane retired */
+        const uint32_t nactive = (uint32_t)__builtin_popcountll(active);
+        /* a wave that can no longer refill is on the critical path of the launch: give it issue priority */
+        if (dry) __builtin_amdgcn_s_setprio(3);
+        if constexpr (FROM_STREAM) {
+            if (dry && nactive <= evict_at) {
+                /* hand the last few running lanes to the next pass */
+                const T rec4[4] = {o.X, o.Yd, o.cx, o.cyd};
+                T rec[NF];
+                for (int k = 0; k < NF; ++k) rec[k] = rec4[k];
+                writer.append(pixel != kInvalidPixel, pixel, (uint32_t)max_iter - (deadline - wclock), rec);
+                writer.finish();
+                break;
+            }
+            /* records carry their own progress, so deadlines are not monotone: keep the true minimum */
+            next_deadline = wclock + wave_min_u32<T>(pixel != kInvalidPixel ? deadline - wclock : 0xFFFFFFFFu);
+            have_running = true;
+        } else {
+            /* refilled lanes get the LATEST deadline (wclock + max_iter), so the earliest one only
+             * changes when it is reached: no reduction here */
+            if (!have_running) { next_deadline = wclock + (uint32_t)max_iter; have_running = true; }
+        }
+
+        /* ---- iterate until `goal` lanes have finished ---- */
+        const uint32_t goal = (dry || refill_at > nactive) ? nactive : refill_at;   /* queue dry: run the rest out */
+        uint32_t newly = 0;
+        /* lanes whose deadline is reached are interior; then find the next earliest deadline */
+        auto reach_deadline = [&](bool at_or_past) {
+            const bool running = pixel != kInvalidPixel && !fin;
+            const bool hit = running && (at_or_past ? (int32_t)(wclock - deadline) >= 0 : deadline == wclock);
+            if (hit) {
+                esc_i = max_iter; esc_r2 = T(0); fin = true;
+                o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+            }
+            newly += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+            const uint32_t rel = wave_min_u32<T>((running && !hit) ? deadline - wclock : 0xFFFFFFFFu);
+            have_running = rel != 0xFFFFFFFFu;
+            next_deadline = wclock + (have_running ? rel : (uint32_t)max_iter);
+        };
+        while (newly < goal) {
+            if (fast) {
+                const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
+#pragma unroll
+                for (int k = 0; k < kFastBlock; ++k) orbit_step(o);
+                const T r2 = orbit_r2(o);
+                if (__builtin_amdgcn_ballot_w64(!(r2 <= B2)) == 0ull) {
+                    wclock += (uint32_t)kFastBlock;
+                    /* clean block: lanes at or past their deadline never escaped -> interior */
+                    if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
+                    continue;
+                }
+                o.X = sX; o.Yd = sYd; o.x2 = sx2; o.y2d = sy2d;      /* roll back, replay tested */
+                fast = false;
+            }
+            bool any_escape = false;
+            for (int k = 0; k < kFastBlock && newly < goal; ++k) {
+                orbit_step(o);
+                const T r2 = orbit_r2(o);
+                const bool e = r2 > B2;
+                const uint64_t em = __builtin_amdgcn_ballot_w64(e);
+                if (em != 0ull) {
+                    if (e) {
+                        esc_i = (int)(wclock - (deadline - (uint32_t)max_iter));
+                        esc_r2 = r2;
+                        fin = true;
+                        o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                    }
+                    newly += (uint32_t)__builtin_popcountll(em);
+                    any_escape = true;
+                }
+                ++wclock;
+                if (wclock == next_deadline) reach_deadline(false);
+            }
+            fast = fast_ok && !any_escape;
+        }
+    }
     diag_write(A, lane, diag_t0, diag_items, diag_claims);
 }
 

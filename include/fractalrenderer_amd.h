@@ -196,8 +196,13 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "workgroups_per_cu"  workgroups of 256 threads launched per compute unit
  *   "run_max", "run_min" longest / shortest run of sub-tiles one dequeue may claim
  *   "shift_bias"         signed change of log2 of the guided-run divisor
- *   "staging"            2 = staged (tile pass + survivor stream passes), 1 = single pass,
- *                        0 = automatic (currently the single pass: faster on C2/C3/C4)
+ *   "pool"               2 = lane-pool kernel (lanes are refilled with the next pixel as they finish),
+ *                        1 = off, 0 = automatic;  "pool_refill_at" = idle lanes that trigger a refill;
+ *                        "pool_passes" = lane-pool passes over the survivors (staging 3), "pool_evict_at" =
+ *                        running lanes at or below which a wave hands its leftovers to the next pass
+ *   "staging"            3 = tile pass for the first "stage_first" iterations + ONE lane-pool pass over the
+ *                        compacted survivors to max_iter, 2 = tile pass + block stream passes, 1 = single pass,
+ *                        0 = automatic (= 3 wherever it applies: no SSAA, no trap/stripe effects)
  *   "stage_first"        iteration budget of the tile pass (default 32)
  *   "stage_ratio"        budget growth per stream pass (default 4)
  *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue may claim in a stream pass

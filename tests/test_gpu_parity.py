@@ -163,8 +163,8 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
     length, sub-tile shape, staging on/off, first budget, budget ratio) gives byte-identical planes."""
     p, W, H = CASES["seahorse_0008_f64"]
     base = gpu_render(fr, renderer, p, 200, 120)
-    assert renderer.last_stages() == 1                     # the single pass is the default
-    opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "queue_flags", "stream_workgroups_per_cu")
+    assert renderer.last_stages() == 2                     # default: tile pass + lane-pool pass
+    opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "queue_flags", "stream_workgroups_per_cu", "pool_refill_at", "pool_passes", "pool_evict_at")
     try:
         for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
             renderer.set_tuning(wg, run, shape)
@@ -175,11 +175,14 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
         for kw in (dict(staging=1), dict(staging=2), dict(staging=2, stage_first=16), dict(staging=2, stage_first=64, stage_ratio=2),
                    dict(staging=2, stage_ratio=16), dict(staging=2, stage_first=512), dict(staging=2, stream_run_max=1),
                    dict(queue_flags=0x100), dict(queue_flags=0x103), dict(staging=2, queue_flags=0x103),
-                   dict(staging=2, stage_first=16, stage_ratio=2, queue_flags=0x101, stream_workgroups_per_cu=2)):
+                   dict(staging=2, stage_first=16, stage_ratio=2, queue_flags=0x101, stream_workgroups_per_cu=2),
+                   dict(staging=3), dict(staging=3, stage_first=64, pool_refill_at=8), dict(staging=3, stage_first=16, pool_refill_at=64),
+                   dict(staging=3, stream_run_max=1, stream_workgroups_per_cu=1), dict(staging=3, pool_passes=1),
+                   dict(staging=3, pool_passes=5, pool_evict_at=64), dict(staging=3, pool_passes=2, pool_evict_at=1, pool_refill_at=1)):
             for k, v in kw.items():
                 renderer.set_option(k, v)
             cur = gpu_render(fr, renderer, p, 200, 120)
-            assert (renderer.last_stages() > 1) == (kw.get("staging") == 2)
+            assert (renderer.last_stages() > 1) == (kw.get("staging", 3) in (2, 3))
             for a, b in zip(base, cur):
                 assert np.array_equal(a, b), kw
             for k in opts:
@@ -190,6 +193,56 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
             renderer.set_option(k, 0)
 
 
+@pytest.mark.parametrize("refill_at", [1, 7, 32, 64])
+@pytest.mark.parametrize("name", sorted(n for n, (p, _, _) in CASES.items()
+                                         if p.aa <= 1 and not (p.orbit_trap_enabled or p.stripe_enabled or p.interior_style == 2)))
+def test_lane_pool_matches_oracle(fr, renderer, oracle, name, refill_at):
+    """The lane-pool kernel (lanes refilled with the next pixel as they finish) against the oracle and,
+    bitwise, against the tile pass."""
+    p, W, H = CASES[name]
+    try:
+        renderer.set_option("staging", 1)
+        tile = gpu_render(fr, renderer, p, W, H)
+        renderer.set_option("pool", 2)
+        renderer.set_option("pool_refill_at", refill_at)
+        rgba, nu, it = gpu_render(fr, renderer, p, W, H)
+    finally:
+        renderer.set_option("pool", 0)
+        renderer.set_option("pool_refill_at", 0)
+        renderer.set_option("staging", 0)
+    ref = oracle.render(p, W, H)
+    check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
+    for a, b in zip(tile, (rgba, nu, it)):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["c3_julia_f32_centre0", "c2_mandel_f64_mi1024_ragged", "c4_seahorse_deep_f64", "mandel_small_bailout"])
+def test_lane_pool_larger_frames_and_shards(fr, renderer, oracle, name):
+    p, _, _ = CASES[name]
+    W, H = 333, 207
+    try:
+        renderer.set_option("staging", 1)
+        tile = gpu_render(fr, renderer, p, W, H)
+        tile_sh = gpu_render(fr, renderer, p, W, H, shard=fr.Shard(1, 3, 8))
+        renderer.set_option("pool", 2)
+        for shape, flags in ((3, 0), (6, 0x103), (4, 0x100)):
+            renderer.set_tuning(shape=shape)
+            renderer.set_option("queue_flags", flags)
+            pool = gpu_render(fr, renderer, p, W, H)
+            for a, b in zip(tile, pool):
+                assert np.array_equal(a, b)
+        renderer.set_tuning()
+        renderer.set_option("queue_flags", 0)
+        pool_sh = gpu_render(fr, renderer, p, W, H, shard=fr.Shard(1, 3, 8))
+        for a, b in zip(tile_sh, pool_sh):
+            assert np.array_equal(a, b)
+    finally:
+        renderer.set_option("pool", 0)
+        renderer.set_option("queue_flags", 0)
+        renderer.set_option("staging", 0)
+        renderer.set_tuning()
+
+
 @pytest.mark.parametrize("name", ["c3_julia_f32_centre0", "julia_f64_default_c", "c2_mandel_f32_mi1024",
                                   "c4_seahorse_deep_f64", "mandel_small_bailout", "mandel_big_bailout",
                                   "julia_c_outside_bailout", "mandel_scale_offset"])
@@ -198,17 +251,22 @@ def test_staged_equals_single_pass(fr, renderer, oracle, name):
     frame large enough that rings wrap, blocks are partially filled and several stages run."""
     p, _, _ = CASES[name]
     W, H = 333, 207
-    single = gpu_render(fr, renderer, p, W, H)
-    assert renderer.last_stages() == 1
     try:
-        renderer.set_option("staging", 2)
-        staged = gpu_render(fr, renderer, p, W, H)
-        n = renderer.last_stages()
+        renderer.set_option("staging", 1)
+        single = gpu_render(fr, renderer, p, W, H)
+        assert renderer.last_stages() == 1
     finally:
         renderer.set_option("staging", 0)
-    assert n > 1 or p.max_iterations < 64
-    for a, b in zip(staged, single):
-        assert np.array_equal(a, b)
+    for mode in (2, 3, 0):                 # 2: block stream passes, 3: one lane-pool pass over the survivors
+        try:
+            renderer.set_option("staging", mode)
+            staged = gpu_render(fr, renderer, p, W, H)
+            n = renderer.last_stages()
+        finally:
+            renderer.set_option("staging", 0)
+        assert n > 1 or p.max_iterations < 64
+        for a, b in zip(staged, single):
+            assert np.array_equal(a, b), mode
 
 
 def test_export_rgb8(fr, renderer, oracle):
@@ -274,9 +332,13 @@ def test_c2_full_size_properties(fr, renderer, oracle):
         renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
         assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba)
         renderer.set_tuning()
-        renderer.set_option("staging", 2)          # tile pass + survivor stream passes at full size
+        renderer.set_option("staging", 2)          # tile pass + survivor block-stream passes at full size
         renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
         assert renderer.last_stages() == 4
+        assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba)
+        renderer.set_option("staging", 1)          # single pass
+        renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
+        assert renderer.last_stages() == 1
         assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba)
     finally:
         renderer.set_tuning()
