@@ -41,7 +41,7 @@ class fr_params(C.Structure):
         ("orbit_trap_enabled", C.c_int32), ("orbit_trap_radius", C.c_float),
         ("stripe_enabled", C.c_int32), ("stripe_density", C.c_float),
         ("color_brightness", C.c_float), ("color_saturation", C.c_float), ("color_contrast", C.c_float),
-        ("flags", C.c_uint32),
+        ("flags", C.c_uint32), ("use_perturbation", C.c_int32),
     ]
 
 

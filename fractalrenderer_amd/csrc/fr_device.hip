@@ -29,6 +29,9 @@ struct fr_ctx {
     hipEvent_t ev_begin, ev_end;
     bool have_timing;
     uint32_t* d_ctrl;           /* queue heads + stream counters of every stage (kCtrlWords) */
+    void* orbit_host;           /* Deep_Zoom: pinned staging (fp64 orbit + its float narrowing) */
+    float* orbit_dev;           /* Deep_Zoom: reference orbit as float pairs */
+    size_t orbit_cap;           /* capacity in scalars (2 per orbit point) */
     void* stream_buf[2];        /* ping-pong survivor streams */
     size_t stream_bytes;
     uint32_t tune_pool;         /* 0 = automatic (currently off), 1 = off, 2 = on: lane-pool kernel */
@@ -102,6 +105,8 @@ extern "C" void fr_ctx_destroy(fr_ctx* c)
     if (c->scratch) (void)hipFree(c->scratch);
     (void)hipFree(c->d_ctrl);
     for (int k = 0; k < 2; ++k) if (c->stream_buf[k]) (void)hipFree(c->stream_buf[k]);
+    if (c->orbit_host) (void)hipHostFree(c->orbit_host);
+    if (c->orbit_dev) (void)hipFree(c->orbit_dev);
     (void)hipEventDestroy(c->ev_begin);
     (void)hipEventDestroy(c->ev_end);
     (void)hipStreamDestroy(c->stream);
@@ -282,6 +287,77 @@ static uint32_t ceil_log2(uint32_t v)
 static uint32_t* stage_heads(fr_ctx* c, int s) { return c->d_ctrl + (size_t)s * kShards * kShardStrideWords; }
 static uint32_t* stage_counter(fr_ctx* c, int s) { return c->d_ctrl + (size_t)(kMaxStages + s) * kShards * kShardStrideWords; }
 
+/* Deep_Zoom: what VulkanEngine::prepare_deep_zoom_rendering + dispatch do per frame
+ * (src/vk_engine.cpp:215-251, src/compute_effect_manager.h:236-324): recompute the fp64 reference orbit
+ * at the view centre on the host (single point, sequential), narrow it to float pairs
+ * (src/deep_zoom_system.cpp:102-110), upload, launch the perturbation kernel. */
+static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* norm,
+                             uint32_t rows_local, float* rgba, void* nu, int32_t* iter, hipStream_t stream)
+{
+    const int32_t max_iter = p->max_iterations;
+    int32_t ref_iter = 0;
+    if (p->use_perturbation) {
+        const size_t need = (size_t)max_iter * 2;
+        if (need > c->orbit_cap) {
+            /* the pinned staging buffer may still feed an earlier asynchronous upload */
+            FR_HIP_TRY(hipStreamSynchronize(stream));
+            if (c->orbit_host) { (void)hipHostFree(c->orbit_host); c->orbit_host = nullptr; }
+            if (c->orbit_dev) { (void)hipFree(c->orbit_dev); c->orbit_dev = nullptr; }
+            c->orbit_cap = 0;
+            FR_HIP_TRY(hipHostMalloc((void**)&c->orbit_host, need * sizeof(double) + need * sizeof(float)));
+            FR_HIP_TRY(hipMalloc((void**)&c->orbit_dev, need * sizeof(float)));
+            c->orbit_cap = need;
+        } else {
+            FR_HIP_TRY(hipStreamSynchronize(stream));       /* previous upload out of the staging buffer */
+        }
+        double* xy = (double*)c->orbit_host;
+        float* xyf = (float*)(xy + need);
+        int st = fr_reference_orbit(p->center_x, p->center_y, max_iter, xy, &ref_iter);
+        if (st != FR_OK) return st;
+        for (int32_t i = 0; i < 2 * ref_iter; ++i) xyf[i] = (float)xy[i];
+        FR_HIP_TRY(hipMemcpyAsync(c->orbit_dev, xyf, (size_t)ref_iter * 2 * sizeof(float), hipMemcpyHostToDevice, stream));
+    }
+
+    DeepZoomArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cx_hi = (float)p->center_x; a.cx_lo = (float)(p->center_x - (double)a.cx_hi);      /* split_double, :252-257 */
+    a.cy_hi = (float)p->center_y; a.cy_lo = (float)(p->center_y - (double)a.cy_hi);
+    a.zoom_hi = (float)p->zoom;   a.zoom_lo = (float)(p->zoom - (double)a.zoom_hi);
+    a.bailout = p->bailout; a.color_offset = p->color_offset; a.color_scale = p->color_scale;
+    a.palette_mode = p->palette_mode; a.max_iter = max_iter; a.ref_iter = ref_iter;
+    a.W = (int32_t)W; a.H = (int32_t)H; a.rows_local = (int32_t)rows_local;
+    a.part = (int32_t)norm->part; a.nparts = (int32_t)norm->nparts; a.rows_per_strip = (int32_t)norm->rows_per_strip;
+    a.orbit = reinterpret_cast<const float2*>(c->orbit_dev);
+    a.rgba = reinterpret_cast<float4*>(rgba); a.nu = (float*)nu; a.iter = iter;
+
+    QueueArgs& q = a.q;
+    q.heads = stage_heads(c, 0);
+    q.nsx = (W + 7) / 8;
+    q.nsx_shift = -1;
+    q.n_items = q.nsx * ((rows_local + 7) / 8);
+    q.n_blk = (q.n_items + kShardBlock - 1) / kShardBlock;
+    uint32_t bits = ceil_log2(q.n_blk);
+    if (bits < 1) bits = 1;
+    q.n_blk_padded = 1u << bits;
+    q.blk_rev_shift = 32u - bits;
+    uint32_t grid = (uint32_t)c->compute_units * 8u;
+    const uint32_t max_grid = (q.n_items + 3) / 4;
+    if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
+    q.run_shift = ceil_log2(16u * ((grid * 4u + kShards - 1) / kShards));
+    q.run_min = 2; q.run_max = 8; q.flags = 0;
+    c->last_grid = grid;
+    c->last_stages = 1;
+
+    FR_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, kCtrlWords * sizeof(uint32_t), stream));
+    FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
+    hipLaunchKernelGGL((deep_zoom_kernel<3>), dim3(grid), dim3(kBlockThreads), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "deep-zoom kernel launch failed: %s", hipGetErrorString(e));
+    FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
+    c->have_timing = true;
+    return FR_OK;
+}
+
 static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* shard,
                           float* rgba, void* nu, int32_t* iter, hipStream_t stream)
 {
@@ -294,6 +370,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         return fr_set_error(FR_ERR_INVALID_ARG, "shard part %u >= nparts %u", norm.part, norm.nparts);
     const uint32_t rows_local = fr_shard_rows(&norm, H);
     if (rows_local == 0) return FR_OK;           /* this part owns no rows */
+    if (p->fractal_type == FR_FRACTAL_DEEP_ZOOM)
+        return enqueue_deep_zoom(c, p, W, H, &norm, rows_local, rgba, nu, iter, stream);
 
     const bool julia = p->fractal_type == FR_FRACTAL_JULIA;
     const bool f64 = p->precision == FR_PRECISION_F64;
@@ -603,7 +681,7 @@ extern "C" int fr_render_shard(fr_ctx* c, const fr_params* p, uint32_t W, uint32
     if (norm.rows_per_strip == 0) norm.rows_per_strip = (norm.nparts == 1) ? H : 1;
     const size_t npx = (size_t)fr_shard_rows(&norm, H) * W;
     if (npx == 0) return FR_OK;
-    const size_t nu_bytes = p->precision == FR_PRECISION_F64 ? 8 : 4;
+    const size_t nu_bytes = (p->precision == FR_PRECISION_F64 && p->fractal_type != FR_FRACTAL_DEEP_ZOOM) ? 8 : 4;
     const size_t off_nu = npx * 16, off_iter = off_nu + npx * 8, need = off_iter + npx * 4;
     if (need > c->scratch_bytes) {
         if (c->scratch) { (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }

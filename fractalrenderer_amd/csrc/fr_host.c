@@ -65,6 +65,7 @@ int fr_params_default(fr_params* p)
     p->stripe_enabled = 0;  p->stripe_density = 10.0f;                /* :50-51 */
     p->color_brightness = 1.0f;  p->color_saturation = 1.0f;  p->color_contrast = 1.0f;   /* :77-79 */
     p->flags = 0;
+    p->use_perturbation = 0;                                          /* :86 */
     return FR_OK;
 }
 
@@ -86,9 +87,10 @@ int fr_params_validate(const fr_params* p, uint32_t width, uint32_t height)
         return fr_set_error(FR_ERR_INVALID_ARG, "frame %ux%u has 2^31 pixels or more", width, height);
     if (p->fractal_type < 0 || p->fractal_type > FR_FRACTAL_DEEP_ZOOM)
         return fr_set_error(FR_ERR_INVALID_ARG, "unknown fractal_type %d", p->fractal_type);
-    if (p->fractal_type != FR_FRACTAL_MANDELBROT && p->fractal_type != FR_FRACTAL_JULIA)
+    if (p->fractal_type != FR_FRACTAL_MANDELBROT && p->fractal_type != FR_FRACTAL_JULIA &&
+        p->fractal_type != FR_FRACTAL_DEEP_ZOOM)
         return fr_set_error(FR_ERR_UNSUPPORTED,
-                            "fractal_type %d is outside the hot path (Mandelbrot and JuliaSet only)",
+                            "fractal_type %d is outside the hot path (Mandelbrot, JuliaSet and Deep_Zoom only)",
                             p->fractal_type);
     if (p->precision != FR_PRECISION_F32 && p->precision != FR_PRECISION_F64)
         return fr_set_error(FR_ERR_INVALID_ARG, "unknown precision %d", p->precision);
@@ -133,10 +135,41 @@ int fr_pack_push_constants(const fr_params* p, float out[20])
         out[10] = p->color_brightness;  out[11] = p->color_saturation;
         out[12] = p->color_contrast;  out[13] = (float)p->palette_mode;      /* data4, :134-138 */
         return FR_OK;                                                        /* data5 = 0, :139 */
+    case FR_FRACTAL_DEEP_ZOOM: {                                             /* :236-324 */
+        /* split_double, :252-257: hi = float(v), lo = float(v - double(hi)) */
+        const float cxh = (float)p->center_x, cxl = (float)(p->center_x - (double)cxh);
+        const float cyh = (float)p->center_y, cyl = (float)(p->center_y - (double)cyh);
+        const float zh = (float)p->zoom, zl = (float)(p->zoom - (double)zh);
+        out[0] = cxh; out[1] = cxl; out[2] = cyh; out[3] = cyl;             /* data1 */
+        out[4] = zh;  out[5] = zl;  out[6] = (float)p->max_iterations;      /* data2 */
+        out[7] = p->use_perturbation ? 1.0f : 0.0f;
+        out[8] = p->color_offset;  out[9] = p->color_scale;                  /* data3 */
+        out[10] = (float)p->bailout;  out[11] = (float)p->palette_mode;
+        out[12] = (float)p->antialiasing_samples;                            /* data4: samples, reference_iterations, */
+        out[13] = (float)fr_deep_zoom_reference_length(p);                   /*        use_series_approx (0), series_order (3) */
+        out[14] = 0.0f;  out[15] = 3.0f;
+        return FR_OK;                                                        /* data5 = 0 */
+    }
     default:
         return fr_set_error(FR_ERR_UNSUPPORTED, "push-constant packing: fractal_type %d is outside the hot path",
                             p->fractal_type);
     }
+}
+
+/* reference_iterations of a Deep_Zoom render: the trimmed length of the fp64 orbit at the centre,
+ * or 0 when perturbation is off (compute_reference_orbit returns early, src/deep_zoom_system.cpp:364) */
+int32_t fr_deep_zoom_reference_length(const fr_params* p)
+{
+    if (!p || !p->use_perturbation || p->max_iterations < 1) return 0;
+    double zr = 0.0, zi = 0.0;
+    for (int32_t i = 0; i < p->max_iterations; ++i) {
+        const double mag = hypot(zr, zi);
+        if (mag > 2.0 || mag > 1e10 || isnan(mag) || isinf(mag)) return i + 1;
+        const double re = zr * zr - zi * zi, im = zr * zi + zi * zr;
+        zr = re + p->center_x;
+        zi = im + p->center_y;
+    }
+    return p->max_iterations;
 }
 
 /* ---- row strips -------------------------------------------------------------------------------- */

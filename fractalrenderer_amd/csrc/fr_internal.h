@@ -19,6 +19,8 @@ int fr_set_error(int status, const char* fmt, ...)
 #endif
     ;
 
+int32_t fr_deep_zoom_reference_length(const fr_params* p);
+
 /* ---- palette knot table: what the kernels stage into LDS ------------------------------
  * Every palette of the two shaders is "warp t, then a 5-knot piece-wise linear ramp"
  * (shaders/mandelbrot.comp:60-141, shaders/julia.comp:20-181).  The table holds the ramp

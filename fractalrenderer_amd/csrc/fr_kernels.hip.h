@@ -1235,6 +1235,156 @@ pool_kernel(const LaunchArgs A)
     diag_write(A, lane, diag_t0, diag_items, diag_claims);
 }
 
+/* ---- Deep_Zoom: the reference's perturbation shader ------------------------------------------------
+ * shaders/test_deep_zoom.comp restated operation for operation (fp32, float-float centre/zoom, explicit
+ * fma in dd_mul_sf as the shader writes it), quirks included -- see DESIGN.md.  The reference orbit
+ * (fp64 on the host, narrowed to float pairs as src/deep_zoom_system.cpp:102-110 uploads it) is read
+ * with a wave-uniform index, i.e. through the scalar cache.  Sub-tiles from the same sharded queue. */
+struct DeepZoomArgs {
+    float cx_hi, cx_lo, cy_hi, cy_lo, zoom_hi, zoom_lo;
+    float bailout, color_offset, color_scale;
+    int32_t palette_mode, max_iter, ref_iter;
+    int32_t W, H, rows_local, part, nparts, rows_per_strip;
+    const float2* orbit;
+    float4* rgba;
+    float* nu;
+    int32_t* iter;
+    QueueArgs q;
+};
+
+struct FF { float hi, lo; };
+__device__ __forceinline__ FF dd_add_dd(FF a, FF b)                /* :31-39 */
+{
+    const float s = a.hi + b.hi;
+    const float v = s - a.hi;
+    const float t = ((b.hi - v) + (a.hi - (s - v))) + (a.lo + b.lo);
+    FF r; r.hi = s + t; r.lo = t - (r.hi - s); return r;
+}
+__device__ __forceinline__ FF dd_mul_sf(FF a, float b)             /* :41-48 */
+{
+    const float p = a.hi * b;
+    const float e = __builtin_fmaf(a.hi, b, -p);
+    const float lo = __builtin_fmaf(a.lo, b, e);
+    FF r; r.hi = p + lo; r.lo = lo - (r.hi - p); return r;
+}
+__device__ __forceinline__ float fractf(float x) { return x - floorf(x); }
+
+__device__ __forceinline__ void deep_zoom_color(const DeepZoomArgs& A, float iter, float zx, float zy,
+                                                float rgb[3], float& smooth)            /* get_color, :75-103 */
+{
+    float lenz = sqrtf(zx * zx + zy * zy);
+    lenz = fmaxf(lenz, 1e-12f);
+    const float log_zn = logf(lenz);
+    const float nu = logf(log_zn / logf(2.0f)) / logf(2.0f);
+    smooth = iter + 1.0f - nu;
+    const float t = smooth * A.color_scale + A.color_offset;
+    if (A.palette_mode == 0) {                                      /* hsv2rgb(fract(t*0.05), 0.8, 0.9), :66-70 */
+        const float h = fractf(t * 0.05f), s = 0.8f, v = 0.9f;
+        const float K[4] = {1.0f, 2.0f / 3.0f, 1.0f / 3.0f, 3.0f};
+        for (int c = 0; c < 3; ++c) {
+            const float p = fabsf(fractf(h + K[c]) * 6.0f - K[3]);
+            const float q = clamp01(p - K[0]);
+            rgb[c] = v * (K[0] * (1.0f - s) + q * s);
+        }
+    } else if (A.palette_mode == 1) {
+        const float s = fractf(t * 0.03f);
+        rgb[0] = 0.0f * (1.0f - s) + 1.0f * s; rgb[1] = 0.1f * (1.0f - s) + 1.0f * s; rgb[2] = 0.3f * (1.0f - s) + 1.0f * s;
+    } else if (A.palette_mode == 2) {
+        const float s = fractf(t * 0.04f);
+        rgb[0] = 0.1f * (1.0f - s) + 1.0f * s; rgb[1] = 0.0f * (1.0f - s) + 0.8f * s; rgb[2] = 0.0f * (1.0f - s) + 0.0f * s;
+    } else {
+        const float s = fractf(t * 0.02f);
+        rgb[0] = rgb[1] = rgb[2] = s;
+    }
+}
+
+template <int FPW_LOG2>
+__global__ void __launch_bounds__(kBlockThreads)
+deep_zoom_kernel(const DeepZoomArgs A)
+{
+    constexpr int FPW = 1 << FPW_LOG2;
+    constexpr int FPH = kWave / FPW;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const int lx = (int)(lane & (FPW - 1)), ly = (int)(lane >> FPW_LOG2);
+    const int W = A.W, H = A.H, max_iter = A.max_iter, ref_iter = A.ref_iter;
+    const float bailout = fmaxf(2.0f, A.bailout);                   /* :114 */
+    const float bailout_sq = bailout * bailout;
+    const FF center_x = {A.cx_hi, A.cx_lo}, center_y = {A.cy_hi, A.cy_lo}, zoom = {A.zoom_hi, A.zoom_lo};
+    const float aspect = (float)W / (float)H;                       /* :125 */
+    const FF pixel_size = dd_mul_sf(zoom, 4.0f / (float)H);          /* :128 */
+    const int n_ref = max_iter < ref_iter ? max_iter : ref_iter;
+
+    WaveQueue q;
+    q.init(A.q.heads, A.q.n_blk_padded, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, false, lane);
+    uint32_t begin, count, cur_shard;
+    while (q.next(begin, count, cur_shard)) {
+        for (uint32_t j = begin; j < begin + count; ++j) {
+            const uint32_t blk = (j / kShardBlock) * kShards + cur_shard;
+            if (blk >= A.q.n_blk) continue;
+            const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
+            if (sid >= A.q.n_items) continue;
+            const uint32_t sty = sid / A.q.nsx, stx = sid - sty * A.q.nsx;
+            const int px = (int)stx * FPW + lx;
+            const int lrow = (int)sty * FPH + ly;
+            const bool inside = px < W && lrow < A.rows_local;
+            int py = lrow;
+            if (A.nparts != 1) {
+                const int strip = lrow / A.rows_per_strip;
+                py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
+            }
+            const float uvx = (float)px / (float)W, uvy = (float)py / (float)H;          /* :118 */
+            const float offset_x = (uvx - 0.5f) * aspect;                               /* :131-132 */
+            const float offset_y = (uvy - 0.5f);
+            const FF dc_x = dd_mul_sf(pixel_size, offset_x), dc_y = dd_mul_sf(pixel_size, offset_y);   /* :135-136 */
+            const FF c_x_dd = dd_add_dd(center_x, dc_x), c_y_dd = dd_add_dd(center_y, dc_y);          /* :139-140 */
+            const float delta_x = dc_x.hi + dc_x.lo, delta_y = dc_y.hi + dc_y.lo;                      /* :143 */
+            const float c_fx = c_x_dd.hi + c_x_dd.lo, c_fy = c_y_dd.hi + c_y_dd.lo;
+
+            float dzx = 0.0f, dzy = 0.0f;
+            bool live = inside;
+            int esc_i = max_iter;
+            float ezx = 0.0f, ezy = 0.0f;
+            /* perturbed iteration against the reference orbit, :153-173 */
+            for (int i = 0; i < n_ref; ++i) {
+                if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
+                const float2 zr = A.orbit[i];                                            /* wave-uniform index */
+                const float mx = zr.x * dzx - zr.y * dzy, my = zr.x * dzy + zr.y * dzx;
+                const float t1x = mx * 2.0f, t1y = my * 2.0f;
+                const float t2x = dzx * dzx - dzy * dzy, t2y = 2.0f * dzx * dzy;
+                const float ndx = t1x + t2x + delta_x, ndy = t1y + t2y + delta_y;
+                if (live) {
+                    dzx = ndx; dzy = ndy;
+                    const float zfx = zr.x + dzx, zfy = zr.y + dzy;
+                    if (zfx * zfx + zfy * zfy > bailout_sq) { live = false; esc_i = i; ezx = zfx; ezy = zfy; }
+                }
+            }
+            /* continue in plain fp32 for the remaining iterations, :181-203 */
+            float zx, zy;
+            if (ref_iter > 0) { const float2 zl = A.orbit[ref_iter - 1]; zx = zl.x + dzx; zy = zl.y + dzy; }
+            else { zx = c_fx; zy = c_fy; }
+            for (int i = n_ref; i < max_iter; ++i) {
+                if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
+                const float z2x = zx * zx - zy * zy, z2y = 2.0f * zx * zy;
+                const float nx = z2x + c_fx, ny = z2y + c_fy;
+                if (live) {
+                    zx = nx; zy = ny;
+                    if (zx * zx + zy * zy > bailout_sq) { live = false; esc_i = i; ezx = zx; ezy = zy; }
+                }
+            }
+            if (inside) {
+                float rgb[3] = {0.0f, 0.0f, 0.0f};
+                float smooth = (float)max_iter;
+                if (esc_i < max_iter && !((float)esc_i >= (float)max_iter - 0.5f))      /* :76 */
+                    deep_zoom_color(A, (float)esc_i, ezx, ezy, rgb, smooth);
+                const size_t o = (size_t)lrow * (size_t)W + (size_t)px;
+                if (A.rgba) A.rgba[o] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+                if (A.nu) A.nu[o] = smooth;
+                if (A.iter) A.iter[o] = esc_i;
+            }
+        }
+    }
+}
+
 /* ---- 8-bit export: src/vk_engine.cpp:1344-1371 on the GPU ------------------------------------ */
 __global__ void __launch_bounds__(kBlockThreads)
 export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8,

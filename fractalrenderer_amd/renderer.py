@@ -122,7 +122,7 @@ class Renderer:
 
     def _output(self, precision: Precision, rows: int, width: int, rgba, nu, it) -> _capi.fr_output:
         npx = rows * width
-        nu_dtype = "float64" if precision == Precision.F64 else "float32"
+        nu_dtype = "float64" if precision == Precision.F64 else "float32"   # Deep_Zoom callers pass Precision.F32
         kinds = set()
         o = _capi.fr_output()
         for name, x, dt, n in (("rgba", rgba, "float32", npx * 4), ("nu", nu, nu_dtype, npx), ("iter", it, "int32", npx)):

@@ -54,6 +54,7 @@ class FractalState:
     color_brightness: float = 1.0               # :77
     color_saturation: float = 1.0               # :78
     color_contrast: float = 1.0                 # :79
+    use_perturbation: bool = False              # :86  (Deep_Zoom: compute and use the fp64 reference orbit)
 
     def reset(self) -> None:
         """FractalState::reset(), src/fractal_state.h:135-153 (note zoom 1.5, not 3.0)."""

@@ -34,14 +34,15 @@ typedef enum fr_status {
     FR_ERR_INVALID_ARG  = -1,   /* NULL pointer, w/h == 0, max_iter outside [1, 2^24], zoom 0/non-finite ... */
     FR_ERR_NO_DEVICE    = -2,   /* no HIP device / device ordinal out of range */
     FR_ERR_HIP          = -3,   /* a HIP runtime call failed (message has the hipError string) */
-    FR_ERR_UNSUPPORTED  = -4,   /* fractal type outside the hot path (only Mandelbrot, JuliaSet) */
+    FR_ERR_UNSUPPORTED  = -4,   /* fractal type outside the hot path (Mandelbrot, JuliaSet, Deep_Zoom are in) */
     FR_ERR_IO           = -5,   /* .franim file could not be read / written */
     FR_ERR_PARSE        = -6,   /* .franim JSON malformed or a required key is missing */
     FR_ERR_NOMEM        = -7
 } fr_status;
 
-/* FractalType, src/fractal_state.h:6-14 (same numeric values). Only the first two
- * are on the hot path; the others return FR_ERR_UNSUPPORTED. */
+/* FractalType, src/fractal_state.h:6-14 (same numeric values).  Mandelbrot and JuliaSet are the
+ * hot path; Deep_Zoom is the reference's perturbation shader (shaders/test_deep_zoom.comp), restated
+ * with its fp32 float-float arithmetic; the others return FR_ERR_UNSUPPORTED. */
 typedef enum fr_fractal_type {
     FR_FRACTAL_MANDELBROT   = 0,
     FR_FRACTAL_JULIA        = 1,
@@ -94,6 +95,10 @@ typedef struct fr_params {
     float   color_saturation;      /*                   :78    default  1               */
     float   color_contrast;        /*                   :79    default  1               */
     uint32_t flags;                /* FR_FLAG_*                                         */
+    int32_t use_perturbation;      /*                   :86    default  0 (bool).  Deep_Zoom only: 1 = the fp64
+                                      reference orbit at the centre is computed (as prepare_deep_zoom_rendering
+                                      does every frame, src/vk_engine.cpp:215-251) and the shader perturbs
+                                      around it; 0 = empty orbit, plain fp32 iteration                  */
 } fr_params;
 
 /* ---- parameters ------------------------------------------------------------------ */

@@ -194,6 +194,134 @@ void fro_post_chain(float rgb[3], float brightness, float saturation, float cont
 #undef ATAN2
 #undef SIN
 
+/* ------------------------------------------------------------------ Deep_Zoom (perturbation) */
+/* shaders/test_deep_zoom.comp, the shader the host loads for FractalType::Deep_Zoom
+ * (src/compute_effect_manager.cpp:133-135).  fp32 throughout, with float-float ("double-double" in
+ * the shader's words) centre and zoom.  Restated WITH its quirks:
+ *   - the view is  4*zoom/H  c-plane units high (pixel_size = zoom*4/H multiplies a NORMALISED
+ *     offset, :128-136), H times smaller than the Mandelbrot shader's mapping;
+ *   - the perturbation loop pairs dz_{i+1} with z_ref[i] (z_full = z_ref[i] + dz_{i+1}, :154-165);
+ *   - the reference orbit is the fp64 orbit narrowed to float (src/deep_zoom_system.cpp:102-110);
+ *   - no glitch detection, no tonemap/gamma, its own 4 palettes (:73-103). */
+typedef struct { float hi, lo; } ff_t;
+static ff_t dd_add_dd(ff_t a, ff_t b)                              /* :31-39 */
+{
+    const float s = a.hi + b.hi;
+    const float v = s - a.hi;
+    const float t = ((b.hi - v) + (a.hi - (s - v))) + (a.lo + b.lo);
+    ff_t r; r.hi = s + t; r.lo = t - (r.hi - s); return r;
+}
+static ff_t dd_mul_sf(ff_t a, float b)                            /* :41-48 */
+{
+    const float p = a.hi * b;
+    const float e = fmaf(a.hi, b, -p);
+    float lo = fmaf(a.lo, b, e);
+    ff_t r; r.hi = p + lo; r.lo = lo - (r.hi - p); return r;
+}
+static ff_t ff_split(double v)                                     /* src/compute_effect_manager.h:252-257 */
+{
+    ff_t r; r.hi = (float)v; r.lo = (float)(v - (double)r.hi); return r;
+}
+static void hsv2rgb(float h, float s, float v, float out[3])       /* :66-70 */
+{
+    const float K[4] = {1.0f, 2.0f / 3.0f, 1.0f / 3.0f, 3.0f};
+    for (int c = 0; c < 3; ++c) {
+        const float p = fabsf(fract_f(h + K[c]) * 6.0f - K[3]);
+        const float q = clamp01_f(p - K[0]);
+        out[c] = v * (K[0] * (1.0f - s) + q * s);
+    }
+}
+static void dz_get_color(const fro_params* P, float iter, float max_iter, float zx, float zy,
+                         float rgb[3], float* smooth)               /* :75-103 */
+{
+    if (iter >= max_iter - 0.5f) { rgb[0] = rgb[1] = rgb[2] = 0.0f; *smooth = max_iter; return; }
+    float lenz = sqrtf(zx * zx + zy * zy);
+    lenz = fmaxf(lenz, 1e-12f);
+    const float log_zn = logf(lenz);
+    const float nu = logf(log_zn / logf(2.0f)) / logf(2.0f);
+    const float smooth_iter = iter + 1.0f - nu;
+    *smooth = smooth_iter;
+    const float t = smooth_iter * P->color_scale + P->color_offset;
+    const int palette = P->palette_mode;
+    if (palette == 0) hsv2rgb(fract_f(t * 0.05f), 0.8f, 0.9f, rgb);
+    else if (palette == 1) {
+        const float s = fract_f(t * 0.03f);
+        const float a[3] = {0.0f, 0.1f, 0.3f}, b[3] = {1.0f, 1.0f, 1.0f};
+        mix3(a, b, s, rgb);
+    } else if (palette == 2) {
+        const float s = fract_f(t * 0.04f);
+        const float a[3] = {0.1f, 0.0f, 0.0f}, b[3] = {1.0f, 0.8f, 0.0f};
+        mix3(a, b, s, rgb);
+    } else { const float s = fract_f(t * 0.02f); rgb[0] = rgb[1] = rgb[2] = s; }
+}
+
+static void pixel_deep_zoom(const fro_params* P, const float* orbit, int32_t ref_iter,
+                            int32_t px, int32_t py, int32_t W, int32_t H, fro_sample* o)   /* main(), :107-207 */
+{
+    const int32_t max_iter = P->max_iterations;
+    const float bailout = fmaxf(2.0f, P->bailout);                 /* :114 */
+    const float bailout_sq = bailout * bailout;
+    const float uvx = (float)px / (float)W, uvy = (float)py / (float)H;        /* :118 */
+    const ff_t center_x = ff_split(P->center_x), center_y = ff_split(P->center_y), zoom = ff_split(P->zoom);
+    const float aspect = (float)W / (float)H;                     /* :125 */
+    const ff_t pixel_size = dd_mul_sf(zoom, 4.0f / (float)H);      /* :128 */
+    const float offset_x = (uvx - 0.5f) * aspect;                 /* :131-132 */
+    const float offset_y = (uvy - 0.5f);
+    const ff_t dc_x = dd_mul_sf(pixel_size, offset_x), dc_y = dd_mul_sf(pixel_size, offset_y);   /* :135-136 */
+    const ff_t c_x_dd = dd_add_dd(center_x, dc_x), c_y_dd = dd_add_dd(center_y, dc_y);          /* :139-140 */
+    const float delta_x = dc_x.hi + dc_x.lo, delta_y = dc_y.hi + dc_y.lo;                        /* :143 */
+    float dzx = 0.0f, dzy = 0.0f;                                  /* :146 */
+    const int32_t n_ref = max_iter < ref_iter ? max_iter : ref_iter;
+    o->executed = 0;
+    for (int32_t i = 0; i < n_ref; ++i) {                          /* :153-173 */
+        const float zrx = orbit[2 * i], zry = orbit[2 * i + 1];
+        const float mx = zrx * dzx - zry * dzy, my = zrx * dzy + zry * dzx;       /* c_mul(z_ref, dz) */
+        const float t1x = mx * 2.0f, t1y = my * 2.0f;
+        const float t2x = dzx * dzx - dzy * dzy, t2y = 2.0f * dzx * dzy;
+        dzx = t1x + t2x + delta_x;
+        dzy = t1y + t2y + delta_y;
+        const float zfx = zrx + dzx, zfy = zry + dzy;
+        o->executed++;
+        if (zfx * zfx + zfy * zfy > bailout_sq) {
+            float sm;
+            dz_get_color(P, (float)i, (float)max_iter, zfx, zfy, o->rgb, &sm);
+            o->iter = i; o->nu = (double)sm; o->zre = zfx; o->zim = zfy;
+            return;
+        }
+    }
+    float zx = 0.0f, zy = 0.0f;                                    /* :181-188 */
+    const float c_fx = c_x_dd.hi + c_x_dd.lo, c_fy = c_y_dd.hi + c_y_dd.lo;
+    if (ref_iter > 0) { zx = orbit[2 * (ref_iter - 1)] + dzx; zy = orbit[2 * (ref_iter - 1) + 1] + dzy; }
+    else { zx = c_fx; zy = c_fy; }
+    for (int32_t i = n_ref; i < max_iter; ++i) {                   /* :190-203 */
+        const float z2x = zx * zx - zy * zy, z2y = 2.0f * zx * zy;
+        zx = z2x + c_fx; zy = z2y + c_fy;
+        o->executed++;
+        if (zx * zx + zy * zy > bailout_sq) {
+            float sm;
+            dz_get_color(P, (float)i, (float)max_iter, zx, zy, o->rgb, &sm);
+            o->iter = i; o->nu = (double)sm; o->zre = zx; o->zim = zy;
+            return;
+        }
+    }
+    o->iter = max_iter; o->nu = (double)max_iter; o->zre = zx; o->zim = zy;
+    o->rgb[0] = o->rgb[1] = o->rgb[2] = 0.0f;                      /* :206 */
+}
+
+/* reference orbit as the shader sees it: fp64 orbit narrowed to float pairs; *len_out = reference_iterations */
+static float* deep_zoom_orbit(const fro_params* P, int32_t* len_out)
+{
+    *len_out = 0;
+    if (!P->use_perturbation) return NULL;                        /* src/deep_zoom_system.cpp:364 */
+    double* xy = (double*)malloc((size_t)P->max_iterations * 2 * sizeof(double));
+    if (!xy) return NULL;
+    const int32_t n = fro_reference_orbit(P->center_x, P->center_y, P->max_iterations, xy);
+    float* f = (float*)malloc((size_t)n * 2 * sizeof(float));
+    if (f) { for (int32_t i = 0; i < 2 * n; ++i) f[i] = (float)xy[i]; *len_out = n; }
+    free(xy);
+    return f;
+}
+
 int32_t fro_max_threads(void)
 {
 #ifdef _OPENMP
@@ -209,6 +337,8 @@ int64_t fro_render_rows(const fro_params* p, int32_t W, int32_t H,
                         double* zre, double* zim, int32_t threads)
 {
     int64_t total = 0;
+    int32_t ref_iter = 0;
+    float* orbit = p->fractal == 5 ? deep_zoom_orbit(p, &ref_iter) : NULL;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
 #else
@@ -221,7 +351,12 @@ int64_t fro_render_rows(const fro_params* p, int32_t W, int32_t H,
             fro_sample first;
             float rgb[3];
             int64_t executed;
-            if (p->precision == 0) pixel_f32(p, x, y, W, H, &first, rgb, &executed);
+            if (p->fractal == 5) {
+                pixel_deep_zoom(p, orbit, ref_iter, x, y, W, H, &first);
+                rgb[0] = first.rgb[0]; rgb[1] = first.rgb[1]; rgb[2] = first.rgb[2];
+                executed = first.executed;
+            }
+            else if (p->precision == 0) pixel_f32(p, x, y, W, H, &first, rgb, &executed);
             else                   pixel_f64(p, x, y, W, H, &first, rgb, &executed);
             total += executed;
             const int64_t o = (int64_t)(y - y0) * W + x;
@@ -232,6 +367,7 @@ int64_t fro_render_rows(const fro_params* p, int32_t W, int32_t H,
             if (zim)  zim[o] = first.zim;
         }
     }
+    free(orbit);
     return total;
 }
 
@@ -240,6 +376,17 @@ int64_t fro_render_rows(const fro_params* p, int32_t W, int32_t H,
 void fro_pack_push_constants(const fro_params* p, float out[20])
 {
     memset(out, 0, 20 * sizeof(float));
+    if (p->fractal == 5) {                                        /* src/compute_effect_manager.h:240-324 */
+        const ff_t cx = ff_split(p->center_x), cy = ff_split(p->center_y), z = ff_split(p->zoom);
+        int32_t n = 0;
+        float* orb = deep_zoom_orbit(p, &n);
+        free(orb);
+        out[0] = cx.hi; out[1] = cx.lo; out[2] = cy.hi; out[3] = cy.lo;
+        out[4] = z.hi; out[5] = z.lo; out[6] = (float)p->max_iterations; out[7] = p->use_perturbation ? 1.0f : 0.0f;
+        out[8] = p->color_offset; out[9] = p->color_scale; out[10] = (float)p->bailout; out[11] = (float)p->palette_mode;
+        out[12] = (float)p->aa; out[13] = (float)n; out[14] = 0.0f; out[15] = 3.0f;   /* series approx off, order 3 (defaults) */
+        return;
+    }
     out[0] = (float)p->center_x;
     out[1] = (float)p->center_y;
     out[2] = (float)p->zoom;

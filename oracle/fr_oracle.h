@@ -36,7 +36,7 @@ extern "C" {
  * Deliberately NOT the product's fr_params: the oracle shares no header with
  * the thing it checks. */
 typedef struct fro_params {
-    int32_t fractal;        /* 0 Mandelbrot, 1 Julia (FractalType, src/fractal_state.h:6-14) */
+    int32_t fractal;        /* 0 Mandelbrot, 1 Julia, 5 Deep_Zoom (FractalType, src/fractal_state.h:6-14) */
     int32_t precision;      /* 0 = fp32 (what the shaders do), 1 = fp64 */
     double  center_x, center_y, zoom;
     int32_t max_iterations;
@@ -52,6 +52,7 @@ typedef struct fro_params {
     float   stripe_density;
     float   brightness, saturation, contrast;
     int32_t post_chain;     /* 0: linear colour, 1: enhance->ACES->gamma (shaders/mandelbrot.comp:233-235) */
+    int32_t use_perturbation;   /* Deep_Zoom (fractal 5): 1 = reference orbit computed and used, 0 = empty orbit */
 } fro_params;
 
 /* Render rows [y0, y1) of a W x H frame.  Any output pointer may be NULL.

@@ -31,7 +31,7 @@ class _FroParams(C.Structure):
         ("orbit_trap_radius", C.c_float), ("stripe_enabled", C.c_int32),
         ("stripe_density", C.c_float),
         ("brightness", C.c_float), ("saturation", C.c_float), ("contrast", C.c_float),
-        ("post_chain", C.c_int32),
+        ("post_chain", C.c_int32), ("use_perturbation", C.c_int32),
     ]
 
 
@@ -60,6 +60,7 @@ class OracleParams:
     saturation: float = 1.0
     contrast: float = 1.0
     post_chain: int = 0
+    use_perturbation: int = 1
 
     def to_c(self) -> _FroParams:
         c = _FroParams()

@@ -55,6 +55,16 @@ CASES = {
                                              bailout=3.0, max_iterations=100, zoom=12.0), 64, 48),
     # view far from the set: every pixel escapes within a few iterations
     "mandel_far_exterior": (OracleParams(center_x=5.0, center_y=5.0, zoom=2.0, max_iterations=64), 40, 40),
+    # Deep_Zoom: the reference's perturbation shader (shaders/test_deep_zoom.comp), fp32 float-float
+    "deepzoom_seahorse": (OracleParams(fractal=5, precision=0, center_x=SEAHORSE[0], center_y=SEAHORSE[1], zoom=1e-6,
+                                       max_iterations=2000, use_perturbation=1), 72, 40),
+    "deepzoom_wide_escaping_reference": (OracleParams(fractal=5, precision=0, center_x=-0.75, center_y=0.1, zoom=100.0,
+                                                      max_iterations=300, use_perturbation=1, palette_mode=1,
+                                                      color_scale=2.0, color_offset=0.5), 64, 64),
+    "deepzoom_no_perturbation": (OracleParams(fractal=5, precision=0, center_x=-0.6, center_y=0.2, zoom=150.0,
+                                              max_iterations=200, use_perturbation=0, palette_mode=2), 56, 40),
+    "deepzoom_gray_small_bailout": (OracleParams(fractal=5, precision=0, center_x=-0.1, center_y=0.65, zoom=120.0,
+                                                 max_iterations=150, use_perturbation=1, palette_mode=7, bailout=1.0), 48, 48),
     # tiny frames
     "mandel_1x1": (OracleParams(), 1, 1),
     "mandel_3x70": (OracleParams(max_iterations=100), 3, 70),

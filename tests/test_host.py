@@ -112,6 +112,26 @@ def test_push_constants_julia(fr, oracle):
     assert e.value.status == fr._capi.FR_ERR_UNSUPPORTED
 
 
+def test_push_constants_deep_zoom(fr, oracle):
+    """src/compute_effect_manager.h:236-324: float-float split of centre/zoom, reference_iterations in data4.y"""
+    for kw in (dict(center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-6, max_iterations=2000, use_perturbation=True),
+               dict(center_x=-0.75, center_y=0.1, zoom=100.0, max_iterations=300, use_perturbation=True, palette_mode=2,
+                    color_offset=0.25, color_scale=3.0, bailout=8.0, antialiasing_samples=2),
+               dict(center_x=0.3, center_y=0.5, zoom=1e-3, max_iterations=100, use_perturbation=False)):
+        s = fr.FractalState(**kw)
+        pc = fr.pack_push_constants(s, fr.FractalType.Deep_Zoom)
+        hi = f32(s.center_x)
+        assert pc[0] == hi and pc[1] == f32(s.center_x - float(hi))
+        assert pc[6] == s.max_iterations and pc[7] == float(s.use_perturbation)
+        n = len(oracle.reference_orbit(s.center_x, s.center_y, s.max_iterations)) if s.use_perturbation else 0
+        assert pc[13] == n and pc[12] == s.antialiasing_samples and pc[15] == 3.0
+        op = oracle.OracleParams(fractal=5, precision=0, center_x=s.center_x, center_y=s.center_y, zoom=s.zoom,
+                                 max_iterations=s.max_iterations, use_perturbation=int(s.use_perturbation),
+                                 palette_mode=s.palette_mode, color_offset=s.color_offset, color_scale=s.color_scale,
+                                 bailout=s.bailout, aa=s.antialiasing_samples)
+        assert oracle.pack_push_constants(op).tobytes() == pc.tobytes()
+
+
 # ---- validation ---------------------------------------------------------------------------------------------
 def test_validation(fr):
     L = fr.lib()
@@ -134,8 +154,9 @@ def test_validation(fr):
     assert st(bailout=0.0) == fr._capi.FR_ERR_INVALID_ARG and st(bailout=math.inf) == fr._capi.FR_ERR_INVALID_ARG
     assert st(antialiasing_samples=17) == fr._capi.FR_ERR_INVALID_ARG and st(antialiasing_samples=0) == 0
     assert st(precision=2) == fr._capi.FR_ERR_INVALID_ARG
-    for t in (fr.FractalType.BurningShip, fr.FractalType.Mandelbulb, fr.FractalType.Phoenix, fr.FractalType.Deep_Zoom):
+    for t in (fr.FractalType.BurningShip, fr.FractalType.Mandelbulb, fr.FractalType.Phoenix):
         assert st(fractal_type=int(t)) == fr._capi.FR_ERR_UNSUPPORTED
+    assert st(fractal_type=int(fr.FractalType.Deep_Zoom)) == 0
     assert st(fractal_type=9) == fr._capi.FR_ERR_INVALID_ARG
     assert b"outside the hot path" in L.fr_last_error() or b"unknown" in L.fr_last_error()
     assert L.fr_status_string(-4) == b"fractal type outside the hot path"

@@ -206,6 +206,32 @@ def test_export_rgb8_kat(oracle):
     assert out[0, 0, 0] == int((a ** (1 / 2.2)) * 255.0) and out[0, 0, 1] == 0
 
 
+# ---- Deep_Zoom (shaders/test_deep_zoom.comp) -----------------------------------------------------------
+def test_deep_zoom_restatement_properties(oracle):
+    """Known structure of the shader's quirks: the view is 4*zoom/H high, the centre pixel has delta 0, and
+    with an empty orbit the loop is a plain fp32 iteration started from z = c."""
+    W = H = 64
+    # centre pixel: offset 0 -> delta 0 -> dz stays 0 -> z_full = reference orbit itself; c = -0.75+0.1i escapes
+    p = oracle.OracleParams(fractal=5, precision=0, center_x=-0.75, center_y=0.1, zoom=100.0, max_iterations=300)
+    f = oracle.render(p, W, H)
+    orb = oracle.reference_orbit(-0.75, 0.1, 300)
+    assert len(orb) < 300                                     # the reference point escapes: orbit trimmed
+    # z_full at iteration i is z_ref[i] (+0): escape when |orbit[i]|^2 > 16 in float
+    of = orb.astype(np.float32)
+    first = next(i for i in range(len(of)) if of[i, 0] * of[i, 0] + of[i, 1] * of[i, 1] > np.float32(16.0)) if \
+        any(of[i, 0] * of[i, 0] + of[i, 1] * of[i, 1] > np.float32(16.0) for i in range(len(of))) else None
+    if first is not None:
+        assert f.iter[H // 2, W // 2] == first
+    # view height: pixel (W/2, 0) has offset_y = -0.5 -> delta_y = -0.5 * zoom*4/H
+    q = oracle.OracleParams(fractal=5, precision=0, center_x=0.0, center_y=0.0, zoom=64.0, max_iterations=1, use_perturbation=0)
+    g = oracle.render(q, W, H)      # empty orbit, one update from z = c: z1 = c^2 + c
+    cy = np.float32(-0.5) * (np.float32(64.0) * (np.float32(4.0) / np.float32(H)))
+    assert g.zre[0, W // 2] == float(np.float32(0.0) * 0 - cy * cy) and g.zim[0, W // 2] == float(cy)
+    # interior is black, alpha 1, nu = max_iter
+    r = oracle.render(oracle.OracleParams(fractal=5, precision=0, center_x=-0.1, center_y=0.0, zoom=1.0, max_iterations=50), 8, 8)
+    assert np.all(r.iter == 50) and np.all(r.rgba[..., :3] == 0) and np.all(r.nu == 50)
+
+
 # ---- golden fixtures ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_golden_frames(oracle, golden, name):
