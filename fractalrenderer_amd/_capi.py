@@ -53,6 +53,10 @@ class fr_shard(C.Structure):
     _fields_ = [("part", C.c_uint32), ("nparts", C.c_uint32), ("rows_per_strip", C.c_uint32)]
 
 
+class fr_png_text(C.Structure):
+    _fields_ = [("key", C.c_char_p), ("text", C.c_char_p)]
+
+
 class fr_anim_info(C.Structure):
     _fields_ = [("duration", C.c_float), ("loop", C.c_int32), ("target_fps", C.c_int32),
                 ("export_width", C.c_int32), ("export_height", C.c_int32), ("keyframe_count", C.c_int32)]
@@ -82,6 +86,11 @@ SIGNATURES = {
     "fr_ctx_last_grid": (C.c_int, [C.c_void_p]),
     "fr_ctx_compute_units": (C.c_int, [C.c_void_p]),
     "fr_export_rgb8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32]),
+    "fr_export_rgb16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32]),
+    "fr_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, _P(fr_png_text), C.c_int32, C.c_int32]),
+    "fr_write_raw_rgb24": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "fr_frame_path": (C.c_int, [C.c_char_p, C.c_int32, C.c_char_p, C.c_size_t]),
+    "fr_render_frame_png": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, C.c_char_p]),
     "fr_anim_load": (C.c_int, [C.c_char_p, _P(C.c_void_p)]),
     "fr_anim_parse": (C.c_int, [C.c_char_p, C.c_size_t, _P(C.c_void_p)]),
     "fr_anim_free": (None, [C.c_void_p]),

@@ -15,6 +15,7 @@ from dataclasses import dataclass
 from typing import Callable, List, Optional
 
 from . import _capi
+from .renderer import frame_path
 from .state import FractalState, FractalType, Precision
 
 
@@ -155,7 +156,7 @@ class AnimationRenderer:
             self.current_frame = frame
             time = anim_system.frame_time(frame)                   # :80
             state = anim_system.interpolate(time)                  # :83
-            path = os.path.join(output_folder, "frame_%06d.png" % frame)   # :86-88
+            path = frame_path(output_folder, frame)                # :86-88
             if not self.render_frame_callback(state, w, h, path):  # :100-107 -> :216
                 return False
             if self.on_frame_complete:

@@ -29,6 +29,8 @@ struct fr_ctx {
     hipEvent_t ev_begin, ev_end;
     bool have_timing;
     uint32_t* d_ctrl;           /* queue heads + stream counters of every stage (kCtrlWords) */
+    void* frame_buf;            /* fr_render_frame_png: RGBA f32 frame + RGB8 */
+    size_t frame_bytes;
     void* orbit_host;           /* Deep_Zoom: pinned staging (fp64 orbit + its float narrowing) */
     float* orbit_dev;           /* Deep_Zoom: reference orbit as float pairs */
     size_t orbit_cap;           /* capacity in scalars (2 per orbit point) */
@@ -105,6 +107,7 @@ extern "C" void fr_ctx_destroy(fr_ctx* c)
     if (c->scratch) (void)hipFree(c->scratch);
     (void)hipFree(c->d_ctrl);
     for (int k = 0; k < 2; ++k) if (c->stream_buf[k]) (void)hipFree(c->stream_buf[k]);
+    if (c->frame_buf) (void)hipFree(c->frame_buf);
     if (c->orbit_host) (void)hipHostFree(c->orbit_host);
     if (c->orbit_dev) (void)hipFree(c->orbit_dev);
     (void)hipEventDestroy(c->ev_begin);
@@ -740,4 +743,78 @@ extern "C" int fr_export_rgb8(fr_ctx* c, const float* rgba, uint32_t W, uint32_t
         FR_HIP_TRY(hipMemcpyAsync(rgb8, d_out, npx * 3, hipMemcpyDeviceToHost, c->stream));
     FR_HIP_TRY(hipStreamSynchronize(c->stream));
     return FR_OK;
+}
+
+extern "C" int fr_export_rgb16(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H,
+                               uint16_t* rgb16, int32_t memory, int32_t through_half)
+{
+    if (!c || !rgba || !rgb16 || W == 0 || H == 0)
+        return fr_set_error(FR_ERR_INVALID_ARG, "fr_export_rgb16: bad argument");
+    FR_HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)W * H;
+    const float4* d_in = reinterpret_cast<const float4*>(rgba);
+    uint16_t* d_out = rgb16;
+    if (memory == FR_MEM_HOST) {
+        const size_t need = npx * 16 + npx * 6;
+        if (need > c->scratch_bytes) {
+            if (c->scratch) { (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+            FR_HIP_TRY(hipMalloc(&c->scratch, need));
+            c->scratch_bytes = need;
+        }
+        FR_HIP_TRY(hipMemcpyAsync(c->scratch, rgba, npx * 16, hipMemcpyHostToDevice, c->stream));
+        d_in = reinterpret_cast<const float4*>(c->scratch);
+        d_out = (uint16_t*)((uint8_t*)c->scratch + npx * 16);
+    } else if (memory != FR_MEM_DEVICE) {
+        return fr_set_error(FR_ERR_INVALID_ARG, "unknown memory kind %d", memory);
+    }
+    size_t blocks = (npx + kBlockThreads - 1) / kBlockThreads;
+    const size_t cap = (size_t)c->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(export_rgb16_kernel, dim3((uint32_t)blocks), dim3(kBlockThreads), 0, c->stream,
+                       d_in, d_out, (int)W, (int)H, (int)through_half);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "export launch failed: %s", hipGetErrorString(e));
+    if (memory == FR_MEM_HOST)
+        FR_HIP_TRY(hipMemcpyAsync(rgb16, d_out, npx * 6, hipMemcpyDeviceToHost, c->stream));
+    FR_HIP_TRY(hipStreamSynchronize(c->stream));
+    return FR_OK;
+}
+
+/* RenderFrameCallback body: src/vk_engine.cpp:1181-1418 (render -> readback -> CPU tonemap/flip -> PNG),
+ * with everything up to the 3 B/pixel readback on the GPU. */
+extern "C" int fr_render_frame_png(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const char* path)
+{
+    if (!c || !p || !path) return fr_set_error(FR_ERR_INVALID_ARG, "fr_render_frame_png: NULL argument");
+    int st = fr_params_validate(p, W, H);
+    if (st != FR_OK) return st;
+    FR_HIP_TRY(hipSetDevice(c->device));
+    const size_t npx = (size_t)W * H;
+    const size_t need = npx * 16 + npx * 3;
+    if (need > c->frame_bytes) {
+        if (c->frame_buf) { (void)hipFree(c->frame_buf); c->frame_buf = nullptr; c->frame_bytes = 0; }
+        FR_HIP_TRY(hipMalloc(&c->frame_buf, need));
+        c->frame_bytes = need;
+    }
+    fr_params q = *p;
+    if (q.fractal_type != FR_FRACTAL_DEEP_ZOOM) q.flags |= FR_FLAG_POST_CHAIN;   /* the storage image holds the post-chained colour;
+                                                                                     the deep-zoom shader has no post chain */
+    float* d_rgba = (float*)c->frame_buf;
+    uint8_t* d_rgb8 = (uint8_t*)c->frame_buf + npx * 16;
+    st = enqueue_render(c, &q, W, H, nullptr, d_rgba, nullptr, nullptr, c->stream);
+    if (st != FR_OK) return st;
+    size_t blocks = (npx + kBlockThreads - 1) / kBlockThreads;
+    const size_t cap = (size_t)c->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(export_rgb8_kernel, dim3((uint32_t)blocks), dim3(kBlockThreads), 0, c->stream,
+                       reinterpret_cast<const float4*>(d_rgba), d_rgb8, (int)W, (int)H, 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "export launch failed: %s", hipGetErrorString(e));
+    uint8_t* host = (uint8_t*)malloc(npx * 3);
+    if (!host) return fr_set_error(FR_ERR_NOMEM, "out of host memory");
+    hipError_t ce = hipMemcpyAsync(host, d_rgb8, npx * 3, hipMemcpyDeviceToHost, c->stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
+    if (ce != hipSuccess) { free(host); return fr_set_error(FR_ERR_HIP, "readback failed: %s", hipGetErrorString(ce)); }
+    st = fr_write_png(path, W, H, 8, host, nullptr, 0, 0);
+    free(host);
+    return st;
 }

@@ -1409,4 +1409,24 @@ export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8,
     }
 }
 
+/* ---- 16-bit export: src/vk_engine.cpp:2054-2073 on the GPU (no second tonemap, clamp, truncate) ---- */
+__global__ void __launch_bounds__(kBlockThreads)
+export_rgb16_kernel(const float4* __restrict__ rgba, uint16_t* __restrict__ rgb16,
+                    int W, int H, int through_half)
+{
+    const size_t n = (size_t)W * (size_t)H;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / (size_t)W), x = (int)(idx - (size_t)y * W);
+        const float4 v = rgba[(size_t)(H - 1 - y) * W + x];                       /* :2058 flip */
+        const float c[3] = {v.x, v.y, v.z};
+        for (int k = 0; k < 3; ++k) {
+            float f = c[k];
+            if (through_half) f = __half2float(__float2half_rn(f));
+            f = f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f);                          /* :2068 */
+            rgb16[idx * 3 + k] = (uint16_t)(f * 65535.0f);                        /* :2069 */
+        }
+    }
+}
+
 }  // namespace fr

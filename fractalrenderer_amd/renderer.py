@@ -11,6 +11,7 @@ kernels behind libfractalrenderer_amd.so.  There is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -169,6 +170,32 @@ class Renderer:
         the Vulkan command buffer / descriptor set arguments become the output planes."""
         self.render(state, int(extent[0]), int(extent[1]), fractal_type=fractal_type, **kw)
 
+    def render_frame(self, state: FractalState, width: int, height: int, path: str,
+                     fractal_type: FractalType = FractalType.Mandelbrot,
+                     precision: Precision = Precision.F32) -> bool:
+        """The RenderFrameCallback itself: bool(const FractalState&, width, height, path)
+        (src/animation_renderer.h:41-48): render, 8-bit export, PNG -- all behind fr_render_frame_png.
+        Returns False on failure, as the reference's callback does."""
+        p = state.to_params(fractal_type, precision)
+        return self._lib.fr_render_frame_png(self._ctx, C.byref(p), width, height, os.fsencode(path)) == _capi.FR_OK
+
+    def export_rgb16(self, rgba, width: int, height: int, out=None, through_half: bool = False):
+        """16-bit export of export_print_quality (src/vk_engine.cpp:2054-2073): clamp, *65535, flip."""
+        p_in, kind_in = self._ptr(rgba, "float32", width * height * 4, "rgba")
+        if out is None:
+            if kind_in == "device":
+                import torch
+                out = torch.empty((height, width, 3), dtype=torch.int16, device=rgba.device)   # torch has no uint16 math: raw bits
+            else:
+                out = np.empty((height, width, 3), np.uint16)
+        want = "int16" if _is_torch(out) else "uint16"
+        p_out, kind_out = self._ptr(out, want, width * height * 3, "rgb16")
+        if kind_in != kind_out:
+            raise ValueError("rgba and rgb16 must live in the same memory kind")
+        mem = _capi.FR_MEM_DEVICE if kind_in == "device" else _capi.FR_MEM_HOST
+        _capi.check(self._lib.fr_export_rgb16(self._ctx, p_in, width, height, p_out, mem, int(through_half)))
+        return out
+
     def export_rgb8(self, rgba, width: int, height: int, out=None, through_half: bool = False):
         """8-bit export of VulkanEngine::render_animation_frame (src/vk_engine.cpp:1344-1371):
         second ACES + gamma, u8 truncation, vertical flip."""
@@ -185,3 +212,33 @@ class Renderer:
         mem = _capi.FR_MEM_DEVICE if kind_in == "device" else _capi.FR_MEM_HOST
         _capi.check(self._lib.fr_export_rgb8(self._ctx, p_in, width, height, p_out, mem, int(through_half)))
         return out
+
+
+def write_png(path: str, rgb: np.ndarray, texts=None, print_metadata: bool = False) -> None:
+    """fr_write_png: (H, W, 3) uint8 or uint16 -> PNG (8-bit: the animation frames, src/vk_engine.cpp:1374-1381;
+    16-bit + print_metadata: the print export, src/vk_engine.cpp:2114-2208)."""
+    a = np.ascontiguousarray(rgb)
+    if a.ndim != 3 or a.shape[2] != 3 or a.dtype not in (np.uint8, np.uint16):
+        raise ValueError("rgb must be (H, W, 3) uint8 or uint16")
+    items = list((texts or {}).items())
+    arr = (_capi.fr_png_text * max(1, len(items)))()
+    keep = []
+    for k, (key, val) in enumerate(items):
+        kb, vb = key.encode("latin-1"), val.encode("latin-1", "replace")
+        keep += [kb, vb]
+        arr[k].key, arr[k].text = kb, vb
+    _capi.check(_capi.lib().fr_write_png(os.fsencode(path), a.shape[1], a.shape[0], 8 * a.dtype.itemsize,
+                                         a.ctypes.data, arr, len(items), int(print_metadata)))
+
+
+def write_raw_rgb24(fd: int, rgb8: np.ndarray) -> None:
+    """fr_write_raw_rgb24: one packed RGB24 frame to a file descriptor (an encoder's stdin pipe)."""
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    _capi.check(_capi.lib().fr_write_raw_rgb24(fd, a.ctypes.data, a.shape[1], a.shape[0]))
+
+
+def frame_path(folder: str, frame: int) -> str:
+    """frame_%06d.png naming of AnimationRenderer::start_render (src/animation_renderer.cpp:86-88)."""
+    buf = C.create_string_buffer(4096)
+    _capi.check(_capi.lib().fr_frame_path(os.fsencode(folder), frame, buf, len(buf)))
+    return os.fsdecode(buf.value)

@@ -236,6 +236,37 @@ int fr_ctx_compute_units(fr_ctx* ctx);
 int fr_export_rgb8(fr_ctx* ctx, const float* rgba, uint32_t width, uint32_t height,
                    uint8_t* rgb8, int32_t memory, int32_t through_half);
 
+/* 16-bit export of VulkanEngine::export_print_quality, src/vk_engine.cpp:2054-2073: per channel
+ * clamp(v, 0, 1) -> (uint16)(v*65535) with a vertical flip and NO second tonemap (unlike the 8-bit path),
+ * RGBA f32 in -> packed RGB16 (host-endian uint16, rows*W*3) out. */
+int fr_export_rgb16(fr_ctx* ctx, const float* rgba, uint32_t width, uint32_t height,
+                    uint16_t* rgb16, int32_t memory, int32_t through_half);
+
+/* ---- frame output (reference f3) ---------------------------------------------------------- */
+
+typedef struct fr_png_text { const char* key; const char* text; } fr_png_text;   /* one tEXt chunk */
+
+/* PNG writer (colour type RGB, no interlace, filter None, zlib deflate).  bit_depth 8: the file
+ * stbi_write_png produces pixel-wise (src/vk_engine.cpp:1374-1381); bit_depth 16: host-endian uint16
+ * samples written big-endian, compression level 9 (src/vk_engine.cpp:2114-2208).  print_metadata != 0
+ * adds what the print export adds: gAMA 1/2.2, sRGB perceptual, pHYs 300 dpi, tIME; `texts` become
+ * uncompressed tEXt chunks. */
+int fr_write_png(const char* path, uint32_t width, uint32_t height, int32_t bit_depth, const void* rgb,
+                 const fr_png_text* texts, int32_t ntexts, int32_t print_metadata);
+
+/* One packed RGB24 frame to a file descriptor (the stdin pipe of an encoder such as
+ * `ffmpeg -f rawvideo -pix_fmt rgb24 -s WxH -i -`, src/video_encoder.cpp:195-224), retrying short writes. */
+int fr_write_raw_rgb24(int fd, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
+/* "<folder>/frame_%06d.png", src/animation_renderer.cpp:86-88 */
+int fr_frame_path(const char* folder, int32_t frame, char* out, size_t cap);
+
+/* The body of the RenderFrameCallback, bool(const FractalState&, width, height, path)
+ * (src/animation_renderer.h:41-48 -> VulkanEngine::render_animation_frame, src/vk_engine.cpp:1181-1418),
+ * end to end on the GPU: render with the shader's post chain (what the rgba16f storage image holds),
+ * round to fp16, second ACES + gamma, u8, vertical flip (:1344-1371), copy 3 B/pixel back, write the PNG. */
+int fr_render_frame_png(fr_ctx* ctx, const fr_params* p, uint32_t width, uint32_t height, const char* path);
+
 /* ---- .franim animations --------------------------------------------------------------- */
 
 typedef struct fr_anim fr_anim;

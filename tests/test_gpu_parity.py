@@ -454,3 +454,32 @@ def test_deep_zoom_larger_frame_and_planes(fr, renderer, oracle):
     rgba, nu, it = gpu_render(fr, renderer, p, W, H, shard=sh)
     check_against(p, ref.iter[rows], ref.nu[rows], ref.rgba[rows], rgba, nu, it)
     assert 0.05 < (ref.iter == 1500).mean() < 0.95          # the view shows both interior and exterior
+
+
+def test_render_frame_png_end_to_end(fr, renderer, oracle, tmp_path):
+    """The RenderFrameCallback body (src/vk_engine.cpp:1181-1418): render + post chain -> fp16 -> second ACES +
+    gamma -> u8 -> flip -> PNG, against the oracle's restatement of the same chain."""
+    from pngdec import read_png
+    for kw, ft in ((dict(max_iterations=200), fr.FractalType.Mandelbrot),
+                   (dict(max_iterations=300, center_x=0.0, julia_c_real=-0.8, julia_c_imag=0.156, palette_mode=6), fr.FractalType.JuliaSet)):
+        W, H = 120, 72
+        path = str(tmp_path / ("f%d.png" % int(ft)))
+        assert renderer.render_frame(fr.FractalState(**kw), W, H, path, fractal_type=ft)
+        px, _ = read_png(path)
+        okw = {("max_iterations" if k == "max_iterations" else k): v for k, v in kw.items()}
+        ref = oracle.render(oracle.OracleParams(fractal=int(ft), precision=0, post_chain=1, **okw), W, H, planes=False)
+        want = oracle.export_rgb8(ref.rgba, through_half=True)
+        d = np.abs(px.astype(np.int16) - want.astype(np.int16))
+        assert px.shape == (H, W, 3) and d.max() <= 1 and (d > 0).mean() < 0.02
+    assert not renderer.render_frame(fr.FractalState(max_iterations=0), 8, 8, str(tmp_path / "bad.png"))
+
+
+def test_export_rgb16(fr, renderer, oracle):
+    p, W, H = CASES["c1_mandel_f64_default"]
+    rgba, _, _ = gpu_render(fr, renderer, p, W, H)
+    got = renderer.export_rgb16(rgba, W, H)
+    want = (np.clip(rgba[::-1, :, :3], 0.0, 1.0) * np.float32(65535.0)).astype(np.uint16)     # src/vk_engine.cpp:2058-2069
+    assert got.dtype == np.uint16 and np.array_equal(got, want)
+    half = renderer.export_rgb16(rgba, W, H, through_half=True)
+    want_h = (np.clip(rgba[::-1, :, :3].astype(np.float16).astype(np.float32), 0.0, 1.0) * np.float32(65535.0)).astype(np.uint16)
+    assert np.array_equal(half, want_h)

@@ -375,3 +375,47 @@ def test_reference_orbit_matches_oracle(fr, oracle):
         ref = oracle.reference_orbit(cx, cy, n)
         assert ln.value == len(ref) and np.array_equal(buf[:ln.value], ref)
     assert L.fr_reference_orbit(0.0, 0.0, 0, buf.ctypes.data, C.byref(ln)) == fr._capi.FR_ERR_INVALID_ARG
+
+
+# ---- frame output (src/vk_engine.cpp:1374-1381, 2114-2208; src/animation_renderer.cpp:86-88) -----------------------
+def test_write_png_8_and_16_bit(fr, tmp_path):
+    import struct
+    from pngdec import read_png
+    rng = np.random.default_rng(3)
+    a8 = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    p8 = str(tmp_path / "a8.png")
+    fr.write_png(p8, a8)
+    px, chunks = read_png(p8)
+    assert np.array_equal(px, a8) and [c[0] for c in chunks] == ["IHDR", "IDAT", "IEND"]
+    a16 = rng.integers(0, 65536, (19, 31, 3), dtype=np.uint16)
+    p16 = str(tmp_path / "a16.png")
+    fr.write_png(p16, a16, texts={"Software": "fractalrenderer_amd", "Center": "(-0.5, 0.0)", "Iterations": "1024"},
+                 print_metadata=True)
+    px, chunks = read_png(p16)
+    assert np.array_equal(px, a16)
+    names = [c[0] for c in chunks]
+    assert names == ["IHDR", "gAMA", "sRGB", "pHYs", "tEXt", "tEXt", "tEXt", "tIME", "IDAT", "IEND"]
+    d = dict(chunks[:4])
+    assert struct.unpack(">I", d["gAMA"])[0] == 45455                       # 1/2.2 (src/vk_engine.cpp:2145)
+    assert d["sRGB"] == b"\x00"                                             # perceptual intent (:2146)
+    assert struct.unpack(">IIB", d["pHYs"]) == (11811, 11811, 1)            # 300 dpi in pixels per metre (:2149-2152)
+    texts = [c[1] for c in chunks if c[0] == "tEXt"]
+    assert texts[0] == b"Software\x00fractalrenderer_amd" and texts[2] == b"Iterations\x001024"
+    with pytest.raises(fr.FractalRendererError):
+        fr.write_png(str(tmp_path / "no" / "dir.png"), a8)
+    with pytest.raises(ValueError):
+        fr.write_png(p8, a8[..., :2])
+
+
+def test_frame_naming_and_raw_pipe(fr):
+    assert fr.frame_path("animation_frames", 0) == "animation_frames/frame_000000.png"
+    assert fr.frame_path("out", 123456) == "out/frame_123456.png"
+    r, w = os.pipe()
+    frame = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    fr.write_raw_rgb24(w, frame)
+    os.close(w)
+    got = os.read(r, 1000)
+    os.close(r)
+    assert got == frame.tobytes()
+    with pytest.raises(fr.FractalRendererError):
+        fr.write_raw_rgb24(-1, frame)
