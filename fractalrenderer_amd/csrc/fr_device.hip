@@ -277,6 +277,18 @@ static hipError_t launch_stream(dim3 grid, hipStream_t s, const LaunchArgs& a)
     return hipGetLastError();
 }
 
+/* run fn(T{}, integral_constant<int, FRACTAL>{}) for the runtime (fractal, precision) */
+template <class Fn>
+static hipError_t by_variant(int fractal, bool f64, Fn&& fn)
+{
+    using std::integral_constant;
+    switch (fractal) {
+    case FR_FRACTAL_JULIA:        return f64 ? fn(double{}, integral_constant<int, 1>{}) : fn(float{}, integral_constant<int, 1>{});
+    case FR_FRACTAL_BURNING_SHIP: return f64 ? fn(double{}, integral_constant<int, 2>{}) : fn(float{}, integral_constant<int, 2>{});
+    default:                      return f64 ? fn(double{}, integral_constant<int, 0>{}) : fn(float{}, integral_constant<int, 0>{});
+    }
+}
+
 static uint32_t ceil_log2(uint32_t v)
 {
     uint32_t b = 0;
@@ -376,9 +388,16 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     if (p->fractal_type == FR_FRACTAL_DEEP_ZOOM)
         return enqueue_deep_zoom(c, p, W, H, &norm, rows_local, rgba, nu, iter, stream);
 
-    const bool julia = p->fractal_type == FR_FRACTAL_JULIA;
+    const int fractal = p->fractal_type;                      /* 0 Mandelbrot, 1 Julia, 2 Burning Ship */
+    const bool julia = fractal == FR_FRACTAL_JULIA;
+    const bool uv_map = fractal != FR_FRACTAL_MANDELBROT;     /* julia.comp:325 / burning_ship.comp:393 viewport map */
     const bool f64 = p->precision == FR_PRECISION_F64;
-    const bool effects = !julia && (p->orbit_trap_enabled || p->stripe_enabled || p->interior_style == 2);
+    /* colourings that need more of the orbit than (escape index, |z|^2): the as-written loops */
+    const bool effects =
+        fractal == FR_FRACTAL_MANDELBROT ? (p->orbit_trap_enabled || p->stripe_enabled || p->interior_style == 2)
+      : fractal == FR_FRACTAL_BURNING_SHIP ? (p->orbit_trap_enabled || (p->stripe_enabled && p->interior_style == 2) ||
+                                              p->interior_style == 3)
+      : false;
     const int max_iter = p->max_iterations;
 
     LaunchArgs a;
@@ -401,7 +420,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.flags = p->flags;
     a.rgba = reinterpret_cast<float4*>(rgba);
     a.nu = nu; a.iter = iter;
-    fr_palette_table_build(julia ? 1 : 0, p->palette_mode, &a.pal);
+    fr_palette_table_build(uv_map ? 1 : 0, p->palette_mode, &a.pal);   /* burning_ship.comp:14-182 == julia.comp:20-181 */
 
     /* escape is absorbing (see escape_run): bailout^2 in [4.5, 1e12], and for Julia |c| <= bailout;
      * Mandelbrot lanes with |c| > bailout retire at i = 0 inside the first, tested block */
@@ -420,7 +439,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.inv_max_iter = 1.0 / (double)max_iter;
     a.inv_log2_bailout = 1.0 / log2((double)p->bailout);
     a.lib_log = !(p->bailout > 1.0f);        /* log2_pos() needs positive arguments: |z|^2 > 1 */
-    a.exact_div_ok = exact_division_ok(c, W, H, julia, f64) ? 1 : 0;
+    a.exact_div_ok = exact_division_ok(c, W, H, uv_map, f64) ? 1 : 0;
 
     /* ---- stage schedule: iteration budgets b0 < b1 < ... < max_iter -------------------------------
      * tile pass runs [0, b0), stream pass k runs [b_{k-1}, b_k).  Default b0 = 32, x4 per stage.
@@ -559,17 +578,15 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.q.run_max = c->tune_run_max ? c->tune_run_max : 16u;
         if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
         a.q.run_shift = clamp_shift((int)ceil_log2(4u * waves_per_shard));
-        if (julia) e = f64 ? launch_pool<double, 1>(shape, dim3(grid), stream, a) : launch_pool<float, 1>(shape, dim3(grid), stream, a);
-        else       e = f64 ? launch_pool<double, 0>(shape, dim3(grid), stream, a) : launch_pool<float, 0>(shape, dim3(grid), stream, a);
-    } else if (julia) {
-        e = f64 ? launch_tile<double, 1, false>(shape, dim3(grid), stream, a)
-                : launch_tile<float, 1, false>(shape, dim3(grid), stream, a);
+        e = by_variant(fractal, f64, [&](auto t, auto f) {
+            return launch_pool<decltype(t), decltype(f)::value>(shape, dim3(grid), stream, a); });
     } else if (effects) {
-        e = f64 ? launch_tile<double, 0, true>(shape, dim3(grid), stream, a)
-                : launch_tile<float, 0, true>(shape, dim3(grid), stream, a);
+        e = by_variant(fractal, f64, [&](auto t, auto f) {
+            constexpr int F = decltype(f)::value == 1 ? 0 : decltype(f)::value;      /* Julia has no effects variant */
+            return launch_tile<decltype(t), F, true>(shape, dim3(grid), stream, a); });
     } else {
-        e = f64 ? launch_tile<double, 0, false>(shape, dim3(grid), stream, a)
-                : launch_tile<float, 0, false>(shape, dim3(grid), stream, a);
+        e = by_variant(fractal, f64, [&](auto t, auto f) {
+            return launch_tile<decltype(t), decltype(f)::value, false>(shape, dim3(grid), stream, a); });
     }
     if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString(e));
 
@@ -612,10 +629,12 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
                  * block): claim several per dequeue so that the records fill whole waves */
                 a.q.run_min = 4u; a.q.run_max = 8u;
             }
-            if (julia) e = f64 ? launch_stream_pool<double, 1>(dim3(sgrid), stream, a) : launch_stream_pool<float, 1>(dim3(sgrid), stream, a);
-            else       e = f64 ? launch_stream_pool<double, 0>(dim3(sgrid), stream, a) : launch_stream_pool<float, 0>(dim3(sgrid), stream, a);
-        } else if (julia) e = f64 ? launch_stream<double, 1>(dim3(sgrid), stream, a) : launch_stream<float, 1>(dim3(sgrid), stream, a);
-        else       e = f64 ? launch_stream<double, 0>(dim3(sgrid), stream, a) : launch_stream<float, 0>(dim3(sgrid), stream, a);
+            e = by_variant(fractal, f64, [&](auto t, auto f) {
+                return launch_stream_pool<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
+        } else {
+            e = by_variant(fractal, f64, [&](auto t, auto f) {
+                return launch_stream<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
+        }
         if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "stream kernel launch failed: %s", hipGetErrorString(e));
     }
     FR_HIP_TRY(hipEventRecord(c->ev_end, stream));

@@ -87,10 +87,9 @@ int fr_params_validate(const fr_params* p, uint32_t width, uint32_t height)
         return fr_set_error(FR_ERR_INVALID_ARG, "frame %ux%u has 2^31 pixels or more", width, height);
     if (p->fractal_type < 0 || p->fractal_type > FR_FRACTAL_DEEP_ZOOM)
         return fr_set_error(FR_ERR_INVALID_ARG, "unknown fractal_type %d", p->fractal_type);
-    if (p->fractal_type != FR_FRACTAL_MANDELBROT && p->fractal_type != FR_FRACTAL_JULIA &&
-        p->fractal_type != FR_FRACTAL_DEEP_ZOOM)
+    if (p->fractal_type == FR_FRACTAL_MANDELBULB || p->fractal_type == FR_FRACTAL_PHOENIX)
         return fr_set_error(FR_ERR_UNSUPPORTED,
-                            "fractal_type %d is outside the hot path (Mandelbrot, JuliaSet and Deep_Zoom only)",
+                            "fractal_type %d is outside the hot path (Mandelbrot, JuliaSet, BurningShip and Deep_Zoom only)",
                             p->fractal_type);
     if (p->precision != FR_PRECISION_F32 && p->precision != FR_PRECISION_F64)
         return fr_set_error(FR_ERR_INVALID_ARG, "unknown precision %d", p->precision);
@@ -116,6 +115,7 @@ int fr_pack_push_constants(const fr_params* p, float out[20])
     for (int i = 0; i < 20; ++i) out[i] = 0.0f;                       /* "= {}", :81 */
     switch (p->fractal_type) {
     case FR_FRACTAL_MANDELBROT:
+    case FR_FRACTAL_BURNING_SHIP:                                            /* same layout, :142-171 */
         out[0] = (float)p->center_x;  out[1] = (float)p->center_y;           /* data1, :86-91 */
         out[2] = (float)p->zoom;      out[3] = (float)p->max_iterations;
         out[4] = p->color_offset;     out[5] = p->color_scale;               /* data2, :92-97 */

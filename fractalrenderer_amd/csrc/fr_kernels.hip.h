@@ -535,10 +535,12 @@ struct Orbit {
     T X, Yd, cx, cyd, x2, y2d;
 };
 
-template <typename T>
+/* ABS (Burning Ship, shaders/burning_ship.comp:241-245): z = abs(z) before the square only changes
+ * the sign of the cross term, 2|zx||zy| = |X|*|Yd|; the abs are VOP3 input modifiers, no extra ops. */
+template <typename T, bool ABS = false>
 __device__ __forceinline__ void orbit_step(Orbit<T>& o)
 {
-    const T p = o.X * o.Yd;
+    const T p = ABS ? Real<T>::fabs(o.X) * Real<T>::fabs(o.Yd) : o.X * o.Yd;
     const T t = Real<T>::fma(T(-0.25), o.y2d, o.x2);
     o.X = t + o.cx;
     o.Yd = Real<T>::fma(T(2), p, o.cyd);
@@ -555,7 +557,7 @@ __device__ __forceinline__ T orbit_r2(const Orbit<T>& o)
 /* Runs the wave's 64 orbits over iterations [i0, i1).  esc_i: escape index, i1 if the lane is
  * still alive after update i1-1 (its orbit state is then the state after i1 updates);
  * esc_r2: |z|^2 at escape.  done_in: lanes that must not run (outside the frame / empty). */
-template <typename T>
+template <typename T, bool ABS = false>
 __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0, const int i1,
                                            const bool fast_ok, const bool start_fast, const uint64_t done_in,
                                            int& esc_i, T& esc_r2)
@@ -572,7 +574,7 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
         if (fast && left >= kFastBlock) {
             const Orbit<T> snap = o;
 #pragma unroll
-            for (int k = 0; k < kFastBlock; ++k) orbit_step(o);
+            for (int k = 0; k < kFastBlock; ++k) orbit_step<T, ABS>(o);
             const T r2 = orbit_r2(o);
             const bool bad = !(r2 <= B2);
             if (__builtin_amdgcn_ballot_w64(bad) == 0ull) { i += kFastBlock; continue; }
@@ -583,7 +585,7 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
         const int n = left < kFastBlock ? left : kFastBlock;
         bool any_escape = false;
         for (int k = 0; k < n; ++k) {
-            orbit_step(o);
+            orbit_step<T, ABS>(o);
             const T r2 = orbit_r2(o);
             const bool e = r2 > B2;
             const uint64_t em = __builtin_amdgcn_ballot_w64(e);
@@ -633,7 +635,47 @@ __device__ __forceinline__ void escape_run_effects(T& zx, T& zy, const T cx, con
     esc_zx = zx; esc_zy = zy;
 }
 
-template <int FRACTAL> struct RecFields { static constexpr int n = FRACTAL == 0 ? 4 : 2; };
+/* As-written Burning Ship loop with its trap / stripe accumulators (shaders/burning_ship.comp:228-256):
+ * used when the colouring needs min_orbit_dist, stripe_value or the final z of an interior sample. */
+template <typename T>
+__device__ __forceinline__ void escape_run_ship_effects(T& zx, T& zy, const T cx, const T cy, const T B2,
+                                                        const int max_iter, const uint64_t done_in,
+                                                        const bool trap, const T trap_radius,
+                                                        const bool stripes, const T stripe_density,
+                                                        int& esc_i, T& esc_r2, T& min_dist, T& stripe_sum)
+{
+    esc_i = max_iter;
+    esc_r2 = T(0);
+    min_dist = T(1e10);
+    stripe_sum = T(0);
+    bool live = true;
+    uint64_t done = done_in;
+    for (int i = 0; i < max_iter; ++i) {
+        if (done == ~0ull) break;
+        if (live) {
+            if (trap) {
+                const T dist = Real<T>::sqrt(zx * zx + zy * zy);
+                min_dist = Real<T>::fmin(min_dist, Real<T>::fabs(dist - trap_radius));
+            }
+            if (stripes) stripe_sum += Real<T>::sin(zy * stripe_density);
+            const T ax = Real<T>::fabs(zx), ay = Real<T>::fabs(zy);
+            const T x = ax * ax - ay * ay + cx;
+            zy = T(2) * ax * ay + cy;
+            zx = x;
+            const T len_sq = zx * zx + zy * zy;
+            if (len_sq > B2) { esc_i = i; esc_r2 = len_sq; live = false; }
+        }
+        done |= __builtin_amdgcn_ballot_w64(!live);
+    }
+}
+
+/* FRACTAL: 0 Mandelbrot, 1 Julia, 2 Burning Ship.  Julia's c is a launch constant, so its survivor
+ * records carry only z; the other two carry c per sample. */
+template <int FRACTAL> struct RecFields { static constexpr int n = FRACTAL == 1 ? 2 : 4; };
+template <int FRACTAL> struct Form {
+    static constexpr bool abs_step = FRACTAL == 2;
+    static constexpr bool per_sample_c = FRACTAL != 1;
+};
 
 __device__ __forceinline__ void diag_write(const LaunchArgs& A, uint32_t lane, uint64_t t0, uint32_t items, uint32_t claims)
 {
@@ -645,8 +687,8 @@ __device__ __forceinline__ void diag_write(const LaunchArgs& A, uint32_t lane, u
 }
 
 /* ---- tile pass ---------------------------------------------------------------------------------
- * FRACTAL: 0 Mandelbrot, 1 Julia.  FPW_LOG2: log2 of the sub-tile width (3: 8x8, 4: 16x4, 6: 64x1).
- * EFFECTS: trap / stripe / interior-style-2 variant (Mandelbrot only, never staged).
+ * FRACTAL: 0 Mandelbrot, 1 Julia, 2 Burning Ship.  FPW_LOG2: log2 of the sub-tile width (3: 8x8, 4: 16x4, 6: 64x1).
+ * EFFECTS: trap / stripe / interior-style variant (Mandelbrot and Burning Ship, never staged).
  * Runs iterations [0, A.i1); when A.i1 < max_iter the samples still alive go to A.out. */
 template <typename T, int FRACTAL, int FPW_LOG2, bool EFFECTS>
 __global__ void __launch_bounds__(kBlockThreads)
@@ -800,7 +842,8 @@ tile_kernel(const LaunchArgs A)
                         }
                     }
                 } else {
-                    /* shaders/julia.comp:325 uv, :221-225 z0, :253-259 sample offsets (sx outer) */
+                    /* shaders/julia.comp:325 uv, :221-225 z0, :253-259 sample offsets (sx outer);
+                     * shaders/burning_ship.comp:393, :322-325, :337-344 are the same map applied to c */
                     T uvx, uvy;
                     if (aa == 1 && A.exact_div_ok) {
                         uvx = div_by<T>((T)px, resx, inv_w);
@@ -818,21 +861,61 @@ tile_kernel(const LaunchArgs A)
                     }
                     const T z0x = center_x + (uvx - T(0.5)) * zoom * aspect;
                     const T z0y = center_y + (uvy - T(0.5)) * zoom;
-                    Orbit<T> o;
-                    o.X = inside ? z0x : T(0);
-                    o.Yd = inside ? T(2) * z0y : T(0);
-                    o.cx = inside ? (T)S.julia_cx : T(0);
-                    o.cyd = inside ? T(2) * (T)S.julia_cy : T(0);
-                    o.x2 = o.X * o.X;
-                    o.y2d = o.Yd * o.Yd;
-                    T r2;
-                    escape_run<T>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2);
-                    alive = staged && inside && it >= i1;
-                    if (staged) {
-                        const T rec[NF] = {o.X, o.Yd};
-                        writer.append(alive, pixel, (uint32_t)i1, rec);
+                    if constexpr (FRACTAL == 2 && EFFECTS) {
+                        T zx = T(0), zy = T(0), r2, min_dist, stripe_sum;
+                        const bool stripes = A.stripe_enabled && A.interior_style == 2;
+                        escape_run_ship_effects<T>(zx, zy, inside ? z0x : T(0), inside ? z0y : T(0), B2, max_iter,
+                                                   outside_mask, A.trap_enabled != 0, (T)S.trap_radius,
+                                                   stripes, (T)S.stripe_density, it, r2, min_dist, stripe_sum);
+                        if (it < max_iter) {
+                            shade<T, 2>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
+                            if (A.trap_enabled && want_rgb) {                 /* burning_ship.comp:302-306 */
+                                const float infl = 1.0f - clamp01((float)min_dist * 2.0f);
+                                float tc[3];
+                                palette_eval(S.pal, infl, tc);
+                                const float k = infl * 0.3f;
+                                for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] * (1.0f - k) + tc[c] * k;
+                            }
+                        } else {                                              /* :259-293 interior styles */
+                            nu = (T)max_iter;
+                            float t = 0.0f, gain = 0.0f;
+                            if (A.interior_style == 1 && A.trap_enabled) {
+                                t = 1.0f - clamp01((float)min_dist * 5.0f); gain = 0.5f;
+                            } else if (stripes) {
+                                t = (float)((stripe_sum / (T)max_iter + T(1)) * T(0.5)); gain = 0.3f;
+                            } else if (A.interior_style == 3) {
+                                t = clamp01((float)Real<T>::sqrt(zx * zx + zy * zy) * 0.5f); gain = 0.4f;
+                            }
+                            if (gain != 0.0f && want_rgb) {
+                                palette_eval(S.pal, t, rgb);
+                                rgb[0] *= gain; rgb[1] *= gain; rgb[2] *= gain;
+                            }
+                        }
+                    } else {
+                        Orbit<T> o;
+                        if constexpr (FRACTAL == 1) {
+                            o.X = inside ? z0x : T(0);
+                            o.Yd = inside ? T(2) * z0y : T(0);
+                            o.cx = inside ? (T)S.julia_cx : T(0);
+                            o.cyd = inside ? T(2) * (T)S.julia_cy : T(0);
+                        } else {
+                            o.X = T(0); o.Yd = T(0);
+                            o.cx = inside ? z0x : T(0);
+                            o.cyd = inside ? T(2) * z0y : T(0);
+                        }
+                        o.x2 = o.X * o.X;
+                        o.y2d = o.Yd * o.Yd;
+                        T r2;
+                        escape_run<T, Form<FRACTAL>::abs_step>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2);
+                        alive = staged && inside && it >= i1;
+                        if (staged) {
+                            const T rec4[4] = {o.X, o.Yd, o.cx, o.cyd};
+                            T rec[NF];
+                            for (int k = 0; k < NF; ++k) rec[k] = rec4[k];
+                            writer.append(alive, pixel, (uint32_t)i1, rec);
+                        }
+                        if (!alive) shade<T, FRACTAL>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
                     }
-                    if (!alive) shade<T, 1>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
                 }
                 if (s == 0) { first_nu = nu; first_it = it; }
                 acc[0] += rgb[0]; acc[1] += rgb[1]; acc[2] += rgb[2];
@@ -843,7 +926,7 @@ tile_kernel(const LaunchArgs A)
                 acc[0] /= n; acc[1] /= n; acc[2] /= n;
             }
             if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
-                post_chain(acc, S.brightness, S.saturation, S.contrast, FRACTAL == 1);
+                post_chain(acc, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
 
             if (inside && !alive) {
                 if (A.rgba) A.rgba[pixel] = make_float4(acc[0], acc[1], acc[2], 1.0f);
@@ -899,7 +982,7 @@ stream_kernel(const LaunchArgs A)
         r.pixel = reinterpret_cast<const uint32_t*>(b)[lane];
         r.X = fields[lane];
         r.Yd = fields[64 + lane];
-        if constexpr (FRACTAL == 0) { r.cx = fields[128 + lane]; r.cyd = fields[192 + lane]; }
+        if constexpr (Form<FRACTAL>::per_sample_c) { r.cx = fields[128 + lane]; r.cyd = fields[192 + lane]; }
         else { r.cx = T(0); r.cyd = T(0); }
         return r;
     };
@@ -919,7 +1002,7 @@ stream_kernel(const LaunchArgs A)
             /* empty lanes of a partial block: z = 0, c = 0 */
             o.X = valid ? cur.X : T(0);
             o.Yd = valid ? cur.Yd : T(0);
-            if constexpr (FRACTAL == 0) {
+            if constexpr (Form<FRACTAL>::per_sample_c) {
                 o.cx = valid ? cur.cx : T(0);
                 o.cyd = valid ? cur.cyd : T(0);
             } else {
@@ -931,11 +1014,11 @@ stream_kernel(const LaunchArgs A)
             int it;
             T r2;
             /* survivors got here without escaping for i0 >= 32 updates: start in unchecked blocks */
-            escape_run<T>(o, B2, A.i0, A.i1, A.fast_ok != 0, true,
+            escape_run<T, Form<FRACTAL>::abs_step>(o, B2, A.i0, A.i1, A.fast_ok != 0, true,
                           __builtin_amdgcn_ballot_w64(!valid), it, r2);
             const bool alive = more && valid && it >= A.i1;
             if (more) {
-                if constexpr (FRACTAL == 0) {
+                if constexpr (Form<FRACTAL>::per_sample_c) {
                     const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
                     writer.append(alive, pixel, (uint32_t)A.i1, rec);
                 } else {
@@ -948,7 +1031,7 @@ stream_kernel(const LaunchArgs A)
                 float rgb[3];
                 shade<T, FRACTAL>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
-                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL == 1);
+                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
                 if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = nu;
                 if (A.iter) A.iter[pixel] = it;
@@ -1062,7 +1145,7 @@ pool_kernel(const LaunchArgs A)
                 float rgb[3];
                 shade<T, FRACTAL>(A, S, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
-                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL == 1);
+                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
                 if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = nu;
                 if (A.iter) A.iter[pixel] = esc_i;
@@ -1098,7 +1181,7 @@ pool_kernel(const LaunchArgs A)
                             const uint32_t done = reinterpret_cast<const uint32_t*>(b)[64 + l];
                             o.X = fields[l];
                             o.Yd = fields[64 + l];
-                            if constexpr (FRACTAL == 0) { o.cx = fields[128 + l]; o.cyd = fields[192 + l]; }
+                            if constexpr (Form<FRACTAL>::per_sample_c) { o.cx = fields[128 + l]; o.cyd = fields[192 + l]; }
                             else { o.cx = (T)S.julia_cx; o.cyd = T(2) * (T)S.julia_cy; }
                             o.x2 = o.X * o.X;
                             o.y2d = o.Yd * o.Yd;
@@ -1142,10 +1225,16 @@ pool_kernel(const LaunchArgs A)
                                 } else {
                                     uvx = (T)px / resx; uvy = (T)py / resy;
                                 }
-                                o.X = center_x + (uvx - T(0.5)) * zoom * aspect;
-                                o.Yd = T(2) * (center_y + (uvy - T(0.5)) * zoom);
-                                o.cx = (T)S.julia_cx;
-                                o.cyd = T(2) * (T)S.julia_cy;
+                                const T mx = center_x + (uvx - T(0.5)) * zoom * aspect;
+                                const T myd = T(2) * (center_y + (uvy - T(0.5)) * zoom);
+                                if constexpr (FRACTAL == 1) {
+                                    o.X = mx; o.Yd = myd;
+                                    o.cx = (T)S.julia_cx;
+                                    o.cyd = T(2) * (T)S.julia_cy;
+                                } else {                          /* shaders/burning_ship.comp:322-325: the map gives c */
+                                    o.X = T(0); o.Yd = T(0);
+                                    o.cx = mx; o.cyd = myd;
+                                }
                                 o.x2 = o.X * o.X;
                                 o.y2d = o.Yd * o.Yd;
                             }
@@ -1199,7 +1288,7 @@ pool_kernel(const LaunchArgs A)
             if (fast) {
                 const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
 #pragma unroll
-                for (int k = 0; k < kFastBlock; ++k) orbit_step(o);
+                for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
                 const T r2 = orbit_r2(o);
                 if (__builtin_amdgcn_ballot_w64(!(r2 <= B2)) == 0ull) {
                     wclock += (uint32_t)kFastBlock;
@@ -1212,7 +1301,7 @@ pool_kernel(const LaunchArgs A)
             }
             bool any_escape = false;
             for (int k = 0; k < kFastBlock && newly < goal; ++k) {
-                orbit_step(o);
+                orbit_step<T, Form<FRACTAL>::abs_step>(o);
                 const T r2 = orbit_r2(o);
                 const bool e = r2 > B2;
                 const uint64_t em = __builtin_amdgcn_ballot_w64(e);

@@ -15,7 +15,8 @@ from . import _capi
 
 
 class FractalType(enum.IntEnum):
-    """src/fractal_state.h:6-14.  Only Mandelbrot and JuliaSet are on the hot path."""
+    """src/fractal_state.h:6-14.  Mandelbrot and JuliaSet are the hot path; BurningShip and Deep_Zoom are
+    its variants (section 8 f1/f4); Mandelbulb and Phoenix are rejected with FR_ERR_UNSUPPORTED."""
     Mandelbrot = 0
     JuliaSet = 1
     BurningShip = 2

@@ -41,8 +41,9 @@ typedef enum fr_status {
 } fr_status;
 
 /* FractalType, src/fractal_state.h:6-14 (same numeric values).  Mandelbrot and JuliaSet are the
- * hot path; Deep_Zoom is the reference's perturbation shader (shaders/test_deep_zoom.comp), restated
- * with its fp32 float-float arithmetic; the others return FR_ERR_UNSUPPORTED. */
+ * hot path; BurningShip (shaders/burning_ship.comp) is the same loop with z = abs(z) before the
+ * square; Deep_Zoom is the reference's perturbation shader (shaders/test_deep_zoom.comp), restated
+ * with its fp32 float-float arithmetic; Mandelbulb and Phoenix return FR_ERR_UNSUPPORTED. */
 typedef enum fr_fractal_type {
     FR_FRACTAL_MANDELBROT   = 0,
     FR_FRACTAL_JULIA        = 1,

@@ -391,7 +391,7 @@ void fro_pack_push_constants(const fro_params* p, float out[20])
     out[1] = (float)p->center_y;
     out[2] = (float)p->zoom;
     out[3] = (float)p->max_iterations;
-    if (p->fractal == 0) {
+    if (p->fractal == 0 || p->fractal == 2) {                     /* Burning Ship packs like Mandelbrot, :142-171 */
         out[4] = p->color_offset; out[5] = p->color_scale; out[6] = (float)p->bailout; out[7] = (float)p->palette_mode;
         out[8] = (float)p->aa; out[9] = (float)p->interior_style;
         out[10] = p->orbit_trap_enabled ? 1.0f : 0.0f; out[11] = p->orbit_trap_radius;

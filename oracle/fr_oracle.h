@@ -36,7 +36,7 @@ extern "C" {
  * Deliberately NOT the product's fr_params: the oracle shares no header with
  * the thing it checks. */
 typedef struct fro_params {
-    int32_t fractal;        /* 0 Mandelbrot, 1 Julia, 5 Deep_Zoom (FractalType, src/fractal_state.h:6-14) */
+    int32_t fractal;        /* 0 Mandelbrot, 1 Julia, 2 Burning Ship, 5 Deep_Zoom (FractalType, src/fractal_state.h:6-14) */
     int32_t precision;      /* 0 = fp32 (what the shaders do), 1 = fp64 */
     double  center_x, center_y, zoom;
     int32_t max_iterations;

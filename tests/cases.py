@@ -55,6 +55,23 @@ CASES = {
                                              bailout=3.0, max_iterations=100, zoom=12.0), 64, 48),
     # view far from the set: every pixel escapes within a few iterations
     "mandel_far_exterior": (OracleParams(center_x=5.0, center_y=5.0, zoom=2.0, max_iterations=64), 40, 40),
+    # Burning Ship (shaders/burning_ship.comp): same loop with z = abs(z) before the square
+    "ship_f64_overview": (OracleParams(fractal=2, center_x=-0.5, center_y=-0.5, zoom=3.5, max_iterations=256), 96, 64),
+    "ship_f32_the_ship": (OracleParams(fractal=2, precision=0, center_x=-1.755, center_y=-0.03, zoom=0.08,
+                                       max_iterations=1024, palette_mode=2), 80, 48),
+    "ship_f64_ragged_mi2048": (OracleParams(fractal=2, center_x=-1.76, center_y=-0.02, zoom=0.12, max_iterations=2048,
+                                            color_scale=4.0, palette_mode=6), 131, 67),
+    "ship_trap_style1_f64": (OracleParams(fractal=2, center_x=-0.5, center_y=-0.5, zoom=3.5, max_iterations=160,
+                                          orbit_trap_enabled=1, orbit_trap_radius=0.6, interior_style=1,
+                                          palette_mode=3), 64, 48),
+    "ship_stripes_style2_f32": (OracleParams(fractal=2, precision=0, center_x=-0.5, center_y=-0.5, zoom=3.5,
+                                             max_iterations=96, stripe_enabled=1, stripe_density=7.0,
+                                             interior_style=2, palette_mode=1), 64, 48),
+    "ship_style3_aa2_post": (OracleParams(fractal=2, center_x=-0.5, center_y=-0.5, zoom=3.5, max_iterations=128,
+                                          interior_style=3, aa=2, post_chain=1, brightness=1.15, contrast=1.3,
+                                          saturation=0.7, palette_mode=8), 40, 32),
+    "ship_small_bailout_f64": (OracleParams(fractal=2, center_x=-0.5, center_y=-0.5, zoom=3.5, max_iterations=200,
+                                            bailout=1.5), 64, 48),
     # Deep_Zoom: the reference's perturbation shader (shaders/test_deep_zoom.comp), fp32 float-float
     "deepzoom_seahorse": (OracleParams(fractal=5, precision=0, center_x=SEAHORSE[0], center_y=SEAHORSE[1], zoom=1e-6,
                                        max_iterations=2000, use_perturbation=1), 72, 40),
@@ -72,3 +89,13 @@ CASES = {
 
 MANDEL_PALETTES = list(range(-1, 8))     # 0..5 defined, others fall back to fire (shaders/mandelbrot.comp:139)
 JULIA_PALETTES = list(range(-1, 12))     # 0..9 defined, others fall back to ultra_fire (shaders/julia.comp:178)
+
+
+def needs_effects(p) -> bool:
+    """Colourings that use more of the orbit than (escape index, |z|^2): rendered by the as-written
+    effects variant of the tile kernel, never staged."""
+    if p.fractal == 0:
+        return bool(p.orbit_trap_enabled or p.stripe_enabled or p.interior_style == 2)
+    if p.fractal == 2:
+        return bool(p.orbit_trap_enabled or (p.stripe_enabled and p.interior_style == 2) or p.interior_style == 3)
+    return False

@@ -13,7 +13,7 @@ Bars:
 import numpy as np
 import pytest
 
-from cases import CASES, MANDEL_PALETTES, JULIA_PALETTES
+from cases import CASES, MANDEL_PALETTES, JULIA_PALETTES, needs_effects
 
 pytestmark = pytest.mark.gpu
 
@@ -96,7 +96,7 @@ def test_case_matches_oracle_and_golden(fr, renderer, oracle, golden, name, shap
 def test_block_boundaries(fr, renderer, oracle, max_iter):
     """max_iter around the 16-iteration block size of the unchecked fast path."""
     for kw in (dict(), dict(fractal=1, center_x=0.0, julia_c_real=-0.8, julia_c_imag=0.156),
-               dict(precision=0), dict(center_x=-0.75, zoom=0.5)):
+               dict(precision=0), dict(center_x=-0.75, zoom=0.5), dict(fractal=2, center_y=-0.5, zoom=3.5)):
         p = oracle.OracleParams(max_iterations=max_iter, **kw)
         rgba, nu, it = gpu_render(fr, renderer, p, 72, 40)
         ref = oracle.render(p, 72, 40)
@@ -153,9 +153,9 @@ def test_row_strip_shards_reassemble(fr, renderer, oracle, nparts, R):
 
 
 def test_all_palettes(fr, renderer, oracle):
-    for fractal, modes in ((0, MANDEL_PALETTES), (1, JULIA_PALETTES)):
+    for fractal, modes in ((0, MANDEL_PALETTES), (1, JULIA_PALETTES), (2, JULIA_PALETTES)):
         for m in modes:
-            p = oracle.OracleParams(fractal=fractal, center_x=-0.5 if fractal == 0 else 0.0, palette_mode=m,
+            p = oracle.OracleParams(fractal=fractal, center_x=0.0 if fractal == 1 else -0.5, palette_mode=m,
                                     max_iterations=96, color_scale=2.5, color_offset=0.1)
             rgba, nu, it = gpu_render(fr, renderer, p, 64, 40)
             ref = oracle.render(p, 64, 40)
@@ -199,8 +199,7 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
 
 @pytest.mark.parametrize("refill_at", [1, 7, 32, 64])
 @pytest.mark.parametrize("name", sorted(n for n, (p, _, _) in CASES.items()
-                                         if p.fractal < 2 and p.aa <= 1
-                                         and not (p.orbit_trap_enabled or p.stripe_enabled or p.interior_style == 2)))
+                                         if p.fractal <= 2 and p.aa <= 1 and not needs_effects(p)))
 def test_lane_pool_matches_oracle(fr, renderer, oracle, name, refill_at):
     """The lane-pool kernel (lanes refilled with the next pixel as they finish) against the oracle and,
     bitwise, against the tile pass."""
@@ -221,7 +220,8 @@ def test_lane_pool_matches_oracle(fr, renderer, oracle, name, refill_at):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("name", ["c3_julia_f32_centre0", "c2_mandel_f64_mi1024_ragged", "c4_seahorse_deep_f64", "mandel_small_bailout"])
+@pytest.mark.parametrize("name", ["c3_julia_f32_centre0", "c2_mandel_f64_mi1024_ragged", "c4_seahorse_deep_f64", "mandel_small_bailout",
+                                  "ship_f32_the_ship"])
 def test_lane_pool_larger_frames_and_shards(fr, renderer, oracle, name):
     p, _, _ = CASES[name]
     W, H = 333, 207
@@ -250,7 +250,8 @@ def test_lane_pool_larger_frames_and_shards(fr, renderer, oracle, name):
 
 @pytest.mark.parametrize("name", ["c3_julia_f32_centre0", "julia_f64_default_c", "c2_mandel_f32_mi1024",
                                   "c4_seahorse_deep_f64", "mandel_small_bailout", "mandel_big_bailout",
-                                  "julia_c_outside_bailout", "mandel_scale_offset"])
+                                  "julia_c_outside_bailout", "mandel_scale_offset", "ship_f32_the_ship",
+                                  "ship_f64_ragged_mi2048", "ship_small_bailout_f64"])
 def test_staged_equals_single_pass(fr, renderer, oracle, name):
     """Survivor compaction (tile pass + stream passes) against the single-pass kernel, bitwise, on a
     frame large enough that rings wrap, blocks are partially filled and several stages run."""

@@ -112,6 +112,24 @@ def test_push_constants_julia(fr, oracle):
     assert e.value.status == fr._capi.FR_ERR_UNSUPPORTED
 
 
+def test_push_constants_burning_ship(fr, oracle):
+    """src/compute_effect_manager.h:142-171: the Mandelbrot layout."""
+    s = fr.FractalState(center_x=-1.755, center_y=-0.03, zoom=0.08, max_iterations=1024, color_offset=0.2,
+                        color_scale=2.0, palette_mode=9, antialiasing_samples=2, interior_style=3,
+                        orbit_trap_enabled=True, orbit_trap_radius=0.6, stripe_enabled=True, stripe_density=7.0,
+                        color_brightness=1.1, color_saturation=0.9, color_contrast=1.2)
+    pc = fr.pack_push_constants(s, fr.FractalType.BurningShip)
+    assert pc.tobytes() == fr.pack_push_constants(s, fr.FractalType.Mandelbrot).tobytes()
+    expect = [f32(-1.755), f32(-0.03), f32(0.08), 1024.0, f32(0.2), 2.0, 4.0, 9.0,
+              2.0, 3.0, 1.0, f32(0.6), 7.0, 1.0, f32(1.1), f32(0.9), f32(1.2), 0, 0, 0]
+    assert pc.tobytes() == np.array(expect, np.float32).tobytes()
+    op = oracle.OracleParams(fractal=2, center_x=-1.755, center_y=-0.03, zoom=0.08, max_iterations=1024,
+                             color_offset=0.2, color_scale=2.0, palette_mode=9, aa=2, interior_style=3,
+                             orbit_trap_enabled=1, orbit_trap_radius=0.6, stripe_enabled=1, stripe_density=7.0,
+                             brightness=1.1, saturation=0.9, contrast=1.2)
+    assert oracle.pack_push_constants(op).tobytes() == pc.tobytes()
+
+
 def test_push_constants_deep_zoom(fr, oracle):
     """src/compute_effect_manager.h:236-324: float-float split of centre/zoom, reference_iterations in data4.y"""
     for kw in (dict(center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-6, max_iterations=2000, use_perturbation=True),
@@ -154,9 +172,9 @@ def test_validation(fr):
     assert st(bailout=0.0) == fr._capi.FR_ERR_INVALID_ARG and st(bailout=math.inf) == fr._capi.FR_ERR_INVALID_ARG
     assert st(antialiasing_samples=17) == fr._capi.FR_ERR_INVALID_ARG and st(antialiasing_samples=0) == 0
     assert st(precision=2) == fr._capi.FR_ERR_INVALID_ARG
-    for t in (fr.FractalType.BurningShip, fr.FractalType.Mandelbulb, fr.FractalType.Phoenix):
+    for t in (fr.FractalType.Mandelbulb, fr.FractalType.Phoenix):
         assert st(fractal_type=int(t)) == fr._capi.FR_ERR_UNSUPPORTED
-    assert st(fractal_type=int(fr.FractalType.Deep_Zoom)) == 0
+    assert st(fractal_type=int(fr.FractalType.Deep_Zoom)) == 0 and st(fractal_type=int(fr.FractalType.BurningShip)) == 0
     assert st(fractal_type=9) == fr._capi.FR_ERR_INVALID_ARG
     assert b"outside the hot path" in L.fr_last_error() or b"unknown" in L.fr_last_error()
     assert L.fr_status_string(-4) == b"fractal type outside the hot path"

@@ -98,6 +98,37 @@ def test_numpy_restatement_mandelbrot(oracle, name):
     assert np.abs(nu.astype(np.float64) - f.nu).max() <= tol
 
 
+@pytest.mark.parametrize("name", ["ship_f64_overview", "ship_f32_the_ship", "ship_f64_ragged_mi2048",
+                                  "ship_small_bailout_f64"])
+def test_numpy_restatement_burning_ship(oracle, name):
+    p, W, H = CASES[name]
+    T = np.float64 if p.precision == 1 else np.float32
+    it, nu, zx, zy = NP.burning_ship(W, H, p.center_x, p.center_y, p.zoom, p.max_iterations, p.bailout, T)
+    f = oracle.render(p, W, H)
+    assert np.array_equal(it, f.iter)
+    assert np.array_equal(zx.astype(np.float64), f.zre) and np.array_equal(zy.astype(np.float64), f.zim)
+    tol = 1e-11 if p.precision == 1 else 4e-4
+    assert np.abs(nu.astype(np.float64) - f.nu).max() <= tol
+
+
+def test_burning_ship_kat(oracle):
+    """Hand-checkable orbits of z <- (|Re z| + i|Im z|)^2 + c (shaders/burning_ship.comp:241-245):
+    c = -1 -> 0, -1, 0, -1 ... (bounded);  c = -1.75 lies on the real antenna (bounded, same as the
+    Mandelbrot real axis since x^2 ignores the fold);  c = 1+i -> z1 = 1+i, z2 = 1+3i, z3 = -7+7i:
+    |z3|^2 = 98 > bailout^2 = 16 at loop index 2."""
+    for cx, cy, expect in ((-1.0, 0.0, 64), (-1.75, 0.0, 64), (1.0, 1.0, 2), (0.0, -1.0, 64)):
+        p = oracle.OracleParams(fractal=2, center_x=cx, center_y=cy, zoom=1e-9, max_iterations=64)
+        f = oracle.render(p, 2, 2)
+        assert int(f.iter[1, 1]) == expect, (cx, cy, f.iter)
+    # escape index 2 at c = 1 + i: nu = 2 + 1 - log2(log(98)/log(4))
+    f = oracle.render(oracle.OracleParams(fractal=2, center_x=1.0, center_y=1.0, zoom=1e-12, max_iterations=64), 2, 2)
+    assert abs(f.nu[1, 1] - (3.0 - np.log2(np.log(98.0) / np.log(4.0)))) < 1e-9
+    # folding breaks the conjugate symmetry Mandelbrot has: c and conj(c) give different orbits
+    up = oracle.render(oracle.OracleParams(fractal=2, center_x=-0.5, center_y=-0.6, zoom=1e-9, max_iterations=256), 2, 2)
+    dn = oracle.render(oracle.OracleParams(fractal=2, center_x=-0.5, center_y=0.6, zoom=1e-9, max_iterations=256), 2, 2)
+    assert up.iter[1, 1] != dn.iter[1, 1]
+
+
 @pytest.mark.parametrize("name", ["c3_julia_f32_centre0", "c3_julia_f32_default_centre", "julia_f64_default_c",
                                   "julia_c_outside_bailout"])
 def test_numpy_restatement_julia(oracle, name):
