@@ -6,9 +6,13 @@
 
 A "step" is one pass of the hot path over one frame of BASELINE.json's metric configuration:
 Mandelbrot 4096x4096, max_iter 1024, fp64, default viewport (configs[1], "C2"), output planes
-resident in HBM.  metric = Mpixels/s (whole job).  At N > 1 the SAME frame is cut into row strips
-dealt round-robin to the ranks, each rank renders its strips and the strips are gathered to rank 0
-over RCCL (strong scaling; gather of frame n overlaps render of frame n+1).
+resident in HBM.  metric = Mpixels/s (whole job).  At N > 1 every frame is cut into row strips dealt
+round-robin to the ranks; the K frames are processed in groups of N, frame g*N + j being gathered to
+rank j by one RCCL all-to-all per group (rotating roots, fractalrenderer_amd/distributed.py
+FrameExchange), double-buffered so that the exchange of group g overlaps the rendering of group g+1.
+The ranks ship the 8-byte smooth-count plane and the destination recolours it (bit-identical to a
+direct render), so every frame ends complete -- RGBA f32 + nu -- in the HBM of one GPU, as at N = 1.
+Strong scaling: the same K frames whatever N.
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline       the metric's own roofline ("achieved HBM GB/s vs peak"): algorithmic bytes
@@ -111,6 +115,10 @@ def main() -> None:
     ap.add_argument("--run-max", type=int, default=0)
     ap.add_argument("--shape", type=int, default=0)
     ap.add_argument("--rows-per-strip", type=int, default=0)
+    ap.add_argument("--payload", default="auto", choices=["auto", "nu", "rgba"],
+                    help="N > 1: plane shipped over xGMI (auto: nu when the colour is a function of nu)")
+    ap.add_argument("--dist-backend", default="nccl", help="rehearsals only: gloo + --same-device on one card")
+    ap.add_argument("--same-device", action="store_true", help="rehearsals only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -118,7 +126,7 @@ def main() -> None:
     import torch.distributed as dist
 
     import fractalrenderer_amd as fr
-    from fractalrenderer_amd.distributed import StripGather
+    from fractalrenderer_amd.distributed import FrameExchange
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,11 +135,16 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     w = WORKLOADS[args.workload]
     W, H = w["W"], w["H"]
@@ -178,20 +191,34 @@ def main() -> None:
         kernel_ms = ev0.elapsed_time(ev1) / args.steps
         last_ms = r.last_kernel_ms()             # the library's own event pair around the last launch
     else:
-        sg = StripGather(W, H, 4, torch.float32, dev, rows_per_strip=args.rows_per_strip)
+        payload = args.payload
+        if payload == "auto":
+            payload = "nu" if r.colorize_supported(state, ftype, prec) else "rgba"
+        nu_dtype = torch.float64 if prec == fr.Precision.F64 else torch.float32
+        fx = FrameExchange(W, H, payload=payload, nu_dtype=nu_dtype, device=dev, rows_per_strip=args.rows_per_strip)
 
-        def render_fn(shard, out, _frame):
-            r.render(state, W, H, fractal_type=ftype, precision=prec, rgba=out, shard=shard, sync=False,
-                     stream=torch.cuda.current_stream().cuda_stream)
+        def render_fn(shard, out, _frame, plane):
+            kw = {"nu": out} if plane == "nu" else {"rgba": out}
+            r.render(state, W, H, fractal_type=ftype, precision=prec, shard=shard, sync=False,
+                     stream=torch.cuda.current_stream().cuda_stream, **kw)
 
-        for k in range(args.warmup):
-            sg.submit(render_fn, k)
-        sg.drain()
+        def colorize_fn(nu_frame, rgba_frame, _frame):
+            r.colorize(state, nu_frame, rgba_frame, fractal_type=ftype, precision=prec,
+                       stream=torch.cuda.current_stream().cuda_stream)
+
+        def run(nframes):
+            f = 0
+            while f < nframes:                       # groups of `world` frames; the last one may be partial
+                count = min(world, nframes - f)
+                fx.submit_group(render_fn, f, count, colorize_fn if payload == "nu" else None)
+                f += count
+            fx.drain()
+
+        fx.prime()                                   # peer connections are set up outside the timed region
+        run(args.warmup)
         barrier()
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            sg.submit(render_fn, k)
-        sg.drain()
+        run(args.steps)
         barrier()
         dt = time.perf_counter() - t0
         last_ms = r.last_kernel_ms()
@@ -212,8 +239,10 @@ def main() -> None:
             "scaling": "strong",
             "vs_baseline": None, "dtype": "f64" if prec == fr.Precision.F64 else "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "output": "RGBA f32 linear colour, 16 B/pixel, resident in HBM",
-                       "parallelism": (f"row strips of {sg.R} rows round-robin over {world} GPUs + RCCL gather to rank 0, "
-                                       "double-buffered" if world > 1 else "1 GPU, persistent tile queue"),
+                       "parallelism": (f"row strips of {fx.R} rows round-robin over {world} GPUs; frames in groups of {world}, "
+                                       f"frame g*{world}+j gathered to rank j by one RCCL all-to-all per group "
+                                       f"(payload: {payload} plane, {'recoloured at the destination, ' if payload == 'nu' else ''}"
+                                       "double-buffered)" if world > 1 else "1 GPU, persistent tile queue"),
                        "compute_units": r.compute_units},
         }
         if world == 1:

@@ -85,6 +85,8 @@ SIGNATURES = {
     "fr_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "fr_ctx_last_grid": (C.c_int, [C.c_void_p]),
     "fr_ctx_compute_units": (C.c_int, [C.c_void_p]),
+    "fr_colorize_supported": (C.c_int, [_P(fr_params)]),
+    "fr_colorize_async": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fr_export_rgb8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32]),
     "fr_export_rgb16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32]),
     "fr_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, _P(fr_png_text), C.c_int32, C.c_int32]),

@@ -373,6 +373,42 @@ static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t
     return FR_OK;
 }
 
+/* the parameter part of the kernel argument block (everything that does not depend on the frame geometry) */
+static void fill_params(LaunchArgs& a, const fr_params* p)
+{
+    const bool f64 = p->precision == FR_PRECISION_F64;
+    memset(&a, 0, sizeof(a));
+    a.center_x = p->center_x; a.center_y = p->center_y; a.zoom = p->zoom;
+    a.julia_cx = p->julia_c_real; a.julia_cy = p->julia_c_imag;
+    a.bailout = p->bailout;
+    a.log_bailout = f64 ? log((double)p->bailout) : (double)logf(p->bailout);
+    a.max_iter = p->max_iterations;
+    a.aa = p->antialiasing_samples;
+    a.palette_mode = p->palette_mode;
+    a.color_offset = p->color_offset; a.color_scale = p->color_scale;
+    a.interior_style = p->interior_style;
+    a.trap_enabled = p->orbit_trap_enabled; a.trap_radius = p->orbit_trap_radius;
+    a.stripe_enabled = p->stripe_enabled; a.stripe_density = p->stripe_density;
+    a.brightness = p->color_brightness; a.saturation = p->color_saturation; a.contrast = p->color_contrast;
+    a.flags = p->flags;
+    /* shaders/mandelbrot.comp numbering for Mandelbrot; burning_ship.comp:14-182 == julia.comp:20-181 */
+    fr_palette_table_build(p->fractal_type != FR_FRACTAL_MANDELBROT ? 1 : 0, p->palette_mode, &a.pal);
+    a.inv_max_iter = 1.0 / (double)p->max_iterations;
+    a.inv_log2_bailout = 1.0 / log2((double)p->bailout);
+    a.lib_log = !(p->bailout > 1.0f);        /* log2_pos() needs positive arguments: |z|^2 > 1 */
+}
+
+/* colourings that need more of the orbit than (escape index, |z|^2): the as-written effects loops */
+static bool needs_effects(const fr_params* p)
+{
+    switch (p->fractal_type) {
+    case FR_FRACTAL_MANDELBROT:   return p->orbit_trap_enabled || p->stripe_enabled || p->interior_style == 2;
+    case FR_FRACTAL_BURNING_SHIP: return p->orbit_trap_enabled || (p->stripe_enabled && p->interior_style == 2) ||
+                                         p->interior_style == 3;
+    default: return false;
+    }
+}
+
 static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* shard,
                           float* rgba, void* nu, int32_t* iter, hipStream_t stream)
 {
@@ -392,35 +428,16 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const bool julia = fractal == FR_FRACTAL_JULIA;
     const bool uv_map = fractal != FR_FRACTAL_MANDELBROT;     /* julia.comp:325 / burning_ship.comp:393 viewport map */
     const bool f64 = p->precision == FR_PRECISION_F64;
-    /* colourings that need more of the orbit than (escape index, |z|^2): the as-written loops */
-    const bool effects =
-        fractal == FR_FRACTAL_MANDELBROT ? (p->orbit_trap_enabled || p->stripe_enabled || p->interior_style == 2)
-      : fractal == FR_FRACTAL_BURNING_SHIP ? (p->orbit_trap_enabled || (p->stripe_enabled && p->interior_style == 2) ||
-                                              p->interior_style == 3)
-      : false;
+    const bool effects = needs_effects(p);
     const int max_iter = p->max_iterations;
 
     LaunchArgs a;
-    memset(&a, 0, sizeof(a));
-    a.center_x = p->center_x; a.center_y = p->center_y; a.zoom = p->zoom;
-    a.julia_cx = p->julia_c_real; a.julia_cy = p->julia_c_imag;
-    a.bailout = p->bailout;
-    a.log_bailout = f64 ? log((double)p->bailout) : (double)logf(p->bailout);
-    a.max_iter = max_iter;
+    fill_params(a, p);
     a.W = (int32_t)W; a.H = (int32_t)H;
     a.rows_local = (int32_t)rows_local;
     a.part = (int32_t)norm.part; a.nparts = (int32_t)norm.nparts; a.rows_per_strip = (int32_t)norm.rows_per_strip;
-    a.aa = p->antialiasing_samples;
-    a.palette_mode = p->palette_mode;
-    a.color_offset = p->color_offset; a.color_scale = p->color_scale;
-    a.interior_style = p->interior_style;
-    a.trap_enabled = p->orbit_trap_enabled; a.trap_radius = p->orbit_trap_radius;
-    a.stripe_enabled = p->stripe_enabled; a.stripe_density = p->stripe_density;
-    a.brightness = p->color_brightness; a.saturation = p->color_saturation; a.contrast = p->color_contrast;
-    a.flags = p->flags;
     a.rgba = reinterpret_cast<float4*>(rgba);
     a.nu = nu; a.iter = iter;
-    fr_palette_table_build(uv_map ? 1 : 0, p->palette_mode, &a.pal);   /* burning_ship.comp:14-182 == julia.comp:20-181 */
 
     /* escape is absorbing (see escape_run): bailout^2 in [4.5, 1e12], and for Julia |c| <= bailout;
      * Mandelbrot lanes with |c| > bailout retire at i = 0 inside the first, tested block */
@@ -436,9 +453,6 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.inv_w_f = 1.0f / (float)W;  a.inv_h_f = 1.0f / (float)H;
     a.aspect_d = (double)W / (double)H;
     a.aspect_f = (float)W / (float)H;
-    a.inv_max_iter = 1.0 / (double)max_iter;
-    a.inv_log2_bailout = 1.0 / log2((double)p->bailout);
-    a.lib_log = !(p->bailout > 1.0f);        /* log2_pos() needs positive arguments: |z|^2 > 1 */
     a.exact_div_ok = exact_division_ok(c, W, H, uv_map, f64) ? 1 : 0;
 
     /* ---- stage schedule: iteration budgets b0 < b1 < ... < max_iter -------------------------------
@@ -729,6 +743,48 @@ extern "C" int fr_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, 
 }
 
 /* ---- 8-bit export ------------------------------------------------------------------------------ */
+/* 1 when a frame's colour plane is a function of its smooth-count plane alone (fr_colorize_async) */
+extern "C" int fr_colorize_supported(const fr_params* p)
+{
+    if (!p) return 0;
+    if (p->fractal_type != FR_FRACTAL_MANDELBROT && p->fractal_type != FR_FRACTAL_JULIA &&
+        p->fractal_type != FR_FRACTAL_BURNING_SHIP) return 0;
+    if (needs_effects(p) || p->antialiasing_samples > 1) return 0;
+    /* every escaped sample must have nu < max_iter, so that nu == max_iter identifies the interior:
+     * Mandelbrot nu = i + 1 - log2(log2|z|) needs |z| > 2 with margin; the Julia form subtracts
+     * log2(log|z|^2 / log B) > 1 for any B > 1 */
+    if (p->fractal_type == FR_FRACTAL_MANDELBROT ? !(p->bailout >= 2.5f) : !(p->bailout >= 1.25f)) return 0;
+    return 1;
+}
+
+extern "C" int fr_colorize_async(fr_ctx* c, const fr_params* p, uint64_t n_pixels, const void* nu, float* rgba,
+                                 void* hip_stream)
+{
+    if (!c || !p || !nu || !rgba) return fr_set_error(FR_ERR_INVALID_ARG, "fr_colorize_async: NULL argument");
+    int st = fr_params_validate(p, 1, 1);
+    if (st != FR_OK) return st;
+    if (!fr_colorize_supported(p))
+        return fr_set_error(FR_ERR_UNSUPPORTED, "colour is not a function of the smooth count for these parameters "
+                                                "(effects, SSAA, Deep_Zoom or a small bailout)");
+    if (n_pixels == 0) return FR_OK;
+    FR_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    LaunchArgs a;
+    fill_params(a, p);
+    size_t blocks = ((size_t)n_pixels + kBlockThreads - 1) / kBlockThreads;
+    const size_t cap = (size_t)c->compute_units * 8;
+    if (blocks > cap) blocks = cap;
+    const size_t n = (size_t)n_pixels;
+    float4* out = reinterpret_cast<float4*>(rgba);
+    hipError_t e = by_variant(p->fractal_type, p->precision == FR_PRECISION_F64, [&](auto t, auto f) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((colorize_kernel<T, decltype(f)::value>), dim3((uint32_t)blocks), dim3(kBlockThreads), 0,
+                           stream, a, reinterpret_cast<const T*>(nu), out, n);
+        return hipGetLastError(); });
+    if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "colorize launch failed: %s", hipGetErrorString(e));
+    return FR_OK;
+}
+
 extern "C" int fr_export_rgb8(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H,
                               uint8_t* rgb8, int32_t memory, int32_t through_half)
 {

@@ -281,6 +281,30 @@ __device__ __forceinline__ void post_chain(float rgb[3], float brightness, float
     for (int k = 0; k < 3; ++k) rgb[k] = pow01(aces(c[k]), 1.0f / 2.2f);
 }
 
+/* Colour of a finished sample from its smooth count alone (no trap/stripe effects): the part of the
+ * shaders after nu is known.  Mandelbrot: shaders/mandelbrot.comp:179-190; Julia: shaders/julia.comp:243-248;
+ * Burning Ship: shaders/burning_ship.comp:259-299 (interior style 0 / no accumulators).
+ * Shared by the render kernels and by colorize_kernel, so a frame recoloured from its nu plane is
+ * bit-identical to the frame the render kernels write. */
+template <typename T, int FRACTAL>
+__device__ __forceinline__ void colour_of(const LaunchArgs& A, const LdsBlock& S, const T nu, const bool interior,
+                                          float rgb[3])
+{
+    const T inv_max_iter = (T)A.inv_max_iter;
+    if constexpr (FRACTAL == 0) {
+        T t = nu * inv_max_iter * (T)S.color_scale;                   /* :179 */
+        t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
+        if (!(interior && A.interior_style == 1))                     /* :182-183, :190 */
+            palette_eval(S.pal, pal_arg(t + (T)S.color_offset), rgb);
+    } else {
+        if (!interior) {                                              /* :243-244 interior: black */
+            T t = nu * inv_max_iter;
+            t = (T)S.color_offset + t * (T)S.color_scale;
+            palette_eval(S.pal, pal_arg(t), rgb);
+        }
+    }
+}
+
 /* Smooth count + colour of one finished sample (no trap/stripe effects).  `it` is the escape
  * index, it >= max_iter for a sample that never escaped.
  * Mandelbrot: shaders/mandelbrot.comp:172-190; Julia: shaders/julia.comp:237-248. */
@@ -289,40 +313,50 @@ __device__ __forceinline__ void shade(const LaunchArgs& A, const LdsBlock& S, co
                                       const bool want_nu, const bool want_rgb, T& nu, float rgb[3])
 {
     const int max_iter = S.max_iter;
-    const T inv_max_iter = (T)A.inv_max_iter;
     nu = T(0);
     rgb[0] = rgb[1] = rgb[2] = 0.0f;
     if (!want_nu) return;
-    if constexpr (FRACTAL == 0) {
-        nu = (T)max_iter;                                             /* :172 */
-        if (it < max_iter) {                                          /* :173-177: mu = log2(log2|z|) */
+    nu = (T)max_iter;                                                 /* mandelbrot.comp:172, julia.comp:243 */
+    if (it < max_iter) {
+        if constexpr (FRACTAL == 0) {                                 /* :173-177: mu = log2(log2|z|) */
             if (!A.lib_log) {
                 nu = (T)it + T(1) - log2_pos(T(0.5) * log2_pos(r2));
             } else {
                 const T log_zn = Real<T>::log(r2) / T(2);
                 nu = (T)it + T(1) - Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
             }
-        }
-        if (want_rgb) {
-            T t = nu * inv_max_iter * (T)S.color_scale;               /* :179 */
-            t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
-            if (!(it >= max_iter && A.interior_style == 1))           /* :182-183, :190 */
-                palette_eval(S.pal, pal_arg(t + (T)S.color_offset), rgb);
-        }
-    } else {
-        nu = (T)max_iter;                                             /* :243-244 interior: black */
-        if (it < max_iter) {                                          /* :237-248 */
+        } else {                                                      /* julia.comp:237-248 */
             /* log(log(r2)/log(B))/log 2 == log2(log2(r2) / log2(B)) */
             if (!A.lib_log)
                 nu = (T)it + T(1) - log2_pos(log2_pos(r2) * (T)A.inv_log2_bailout);
             else
                 nu = (T)it + T(1) - Real<T>::log(Real<T>::log(r2) / (T)S.log_bailout) / Real<T>::ln2();
-            if (want_rgb) {
-                T t = nu * inv_max_iter;
-                t = (T)S.color_offset + t * (T)S.color_scale;
-                palette_eval(S.pal, pal_arg(t), rgb);
-            }
         }
+    }
+    if (want_rgb) colour_of<T, FRACTAL>(A, S, nu, it >= max_iter, rgb);
+}
+
+/* ---- recolour from the smooth-count plane ---------------------------------------------------------
+ * rgba[i] = the colour the render kernels write for a sample whose smooth count is nu[i].  Only valid
+ * when the colour is a function of nu alone and "interior" can be read off nu (nu == max_iter): no
+ * effects variant, no SSAA, bailout > 2 so that every escaped sample has nu < max_iter (|z| > 2 gives
+ * log2(log2|z|) > 0; the host enforces this).  HBM-bound: 8 (4) B read + 16 B written per pixel.  Used by
+ * the multi-GPU exchange, which ships the 8-byte nu plane over xGMI instead of the 16-byte colour. */
+template <typename T, int FRACTAL>
+__global__ void __launch_bounds__(kBlockThreads)
+colorize_kernel(const LaunchArgs A, const T* __restrict__ nu_in, float4* __restrict__ rgba, const size_t n)
+{
+    __shared__ LdsBlock S;
+    stage_constants(S, A);
+    const T interior_nu = (T)S.max_iter;
+    const size_t stride = (size_t)gridDim.x * kBlockThreads;
+    for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride) {
+        const T nu = nu_in[i];
+        float rgb[3] = {0.0f, 0.0f, 0.0f};
+        colour_of<T, FRACTAL>(A, S, nu, nu == interior_nu, rgb);
+        if (A.flags & FR_FLAG_POST_CHAIN)
+            post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
+        rgba[i] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
     }
 }
 

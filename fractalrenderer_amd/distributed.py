@@ -153,3 +153,186 @@ class StripGather:
         if self.on_gpu:
             self.compute.synchronize()
             self.comm.synchronize()
+
+
+class FrameExchange:
+    """Row-strip sharded frames of a SEQUENCE, gathered with rotating roots (an all-to-all).
+
+    Why not StripGather for a sequence: a finished frame is 16 B/pixel of colour, one MI355X renders
+    the C2 frame at ~18.5 Gpixel/s = ~300 GB/s of output, and an xGMI link moves ~77 GB/s per
+    direction.  Gathering every frame to ONE root funnels (N-1)/N of all output through the root's
+    N-1 links: at N = 2 the single link is 4x too slow, at N = 8 the root's 7 links still carry only
+    ~1/4 of what 8 GPUs produce.  Two changes remove that wall:
+
+      * rotating roots: frames are processed in groups of N; frame g*N + j is gathered to rank j.
+        Every rank renders its strips of all N frames of the group and ONE all-to-all (RCCL grouped
+        send/recv over the full xGMI mesh) delivers strip set j to rank j, so all N*(N-1) directed
+        links carry traffic instead of the 7 into one root, and each rank ends the group owning one
+        complete frame -- which is also where the per-frame export / PNG work then runs, in parallel;
+      * compact payload: when the colour is a function of the smooth count alone
+        (fr_colorize_supported) the ranks render and ship only the nu plane (8 B/pixel fp64, 4 B fp32)
+        and the destination recolours the assembled frame (fr_colorize_async), bit-identically to a
+        direct render.  Otherwise the 16-byte colour plane is shipped.
+
+    render_fn(shard, out, frame_index, plane) fills `out` (rows_local x W [x 4]) with plane "nu" or
+    "rgba" of `shard` of frame `frame_index`; colorize_fn(nu_frame, rgba_frame, frame_index) recolours.
+    On the GPU path both must only ENQUEUE on the current torch stream.  Double-buffered: the
+    exchange of group g overlaps the rendering of group g+1.
+    """
+
+    def __init__(self, width: int, height: int, *, payload: str = "nu", nu_dtype=torch.float64,
+                 device: Optional[torch.device] = None, rows_per_strip: int = 0, group=None, slots: int = 2,
+                 stage_through_host: Optional[bool] = None):
+        if payload not in ("nu", "rgba"):
+            raise ValueError("payload must be 'nu' or 'rgba'")
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.W, self.H = width, height
+        self.payload = payload
+        self.device = device if device is not None else torch.device("cpu")
+        self.on_gpu = self.device.type == "cuda"
+        self.R = rows_per_strip or pick_rows_per_strip(height, self.world)
+        self.shard = Shard(self.rank, self.world, self.R)
+        self.rows_local = self.shard.rows(height)
+        self.rows_of = [Shard(r, self.world, self.R).rows(height) for r in range(self.world)]
+        self.even = (height % (self.world * self.R) == 0)
+        self.nslots = slots
+        # gloo cannot move device tensors point-to-point: bounce through pinned host memory (rehearsals
+        # of the GPU path on one card; RCCL moves device memory directly)
+        if stage_through_host is None:
+            stage_through_host = self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self.stage = stage_through_host
+        tail = (4,) if payload == "rgba" else ()
+        pdt = torch.float32 if payload == "rgba" else nu_dtype
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.device)  # noqa: E731
+        N = self.world
+        self.send = [mk((N, self.rows_local, width) + tail, pdt) for _ in range(slots)]
+        self.recv = [[mk((self.rows_of[r], width) + tail, pdt) for r in range(N)] for _ in range(slots)]
+        self.frame_nu = [mk((height, width), nu_dtype) for _ in range(slots)] if payload == "nu" else [None] * slots
+        self.frame_rgba = [mk((height, width, 4), torch.float32) for _ in range(slots)]
+        self.frame_index = [-1] * slots          # which frame this rank's slot holds (-1: none)
+        self._index = [torch.from_numpy(Shard(r, N, self.R).global_rows(height)).to(self.device)
+                       for r in range(N)] if not self.even else []
+        if self.stage:
+            pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)  # noqa: E731
+            self._hsend = pin(self.send[0])
+            self._hrecv = [pin(t) for t in self.recv[0]]
+        if self.on_gpu:
+            self.compute = torch.cuda.Stream(device=self.device)
+            self.comm = torch.cuda.Stream(device=self.device)
+            self.rendered = [torch.cuda.Event() for _ in range(slots)]
+            self.delivered = [torch.cuda.Event() for _ in range(slots)]
+            self._used = [False] * slots
+        self._groups = 0
+
+    # -- the exchange of one group: strip set j -> rank j, j < count ------------------------------
+    def _exchange(self, b: int, count: int) -> None:
+        N, me = self.world, self.rank
+        send, recv = self.send[b], self.recv[b]
+        if me < count:
+            recv[me].copy_(send[me])                                     # own strips stay on the card
+        if N == 1:
+            return
+        if self.stage:
+            self._hsend.copy_(send)
+            torch.cuda.current_stream().synchronize()
+            src, dst = self._hsend, self._hrecv
+        else:
+            src, dst = send, recv
+        ops = []
+        for j in range(count):
+            if j != me and self.rows_local:
+                ops.append(dist.P2POp(dist.isend, src[j], j, self.group))
+        if me < count:
+            for r in range(N):
+                if r != me and self.rows_of[r]:
+                    ops.append(dist.P2POp(dist.irecv, dst[r], r, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()              # RCCL: the current stream waits; gloo: the host blocks
+        if self.stage and me < count:
+            for r in range(N):
+                if r != me:
+                    recv[r].copy_(dst[r], non_blocking=True)
+
+    def _assemble(self, b: int, colorize_fn, frame_index: int) -> None:
+        N = self.world
+        frame = self.frame_nu[b] if self.payload == "nu" else self.frame_rgba[b]
+        if self.even:
+            S = self.H // (N * self.R)
+            fv = frame.view((S, N, self.R, self.W) + tuple(frame.shape[2:]))
+            for p, part in enumerate(self.recv[b]):
+                fv[:, p].copy_(part.view((S, self.R, self.W) + tuple(frame.shape[2:])))
+        else:
+            for p, part in enumerate(self.recv[b]):
+                if part.shape[0]:
+                    frame.index_copy_(0, self._index[p], part)
+        if self.payload == "nu":
+            colorize_fn(self.frame_nu[b], self.frame_rgba[b], frame_index)
+
+    def submit_group(self, render_fn: Callable, first_frame: int, count: int,
+                     colorize_fn: Optional[Callable] = None) -> int:
+        """Render and exchange frames first_frame .. first_frame + count - 1 (count <= world); frame
+        first_frame + j lands on rank j.  Returns the slot; this rank's frame (if it got one) is valid
+        after wait(slot) / drain() in frame_rgba[slot] (and frame_nu[slot] for the nu payload)."""
+        if not 1 <= count <= self.world:
+            raise ValueError("a group holds 1..world frames")
+        if self.payload == "nu" and colorize_fn is None:
+            raise ValueError("the nu payload needs a colorize_fn")
+        b = self._groups % self.nslots
+        self._groups += 1
+        mine = first_frame + self.rank if self.rank < count else -1
+
+        def render_all():
+            for j in range(count):
+                if self.rows_local:
+                    render_fn(self.shard, self.send[b][j], first_frame + j, self.payload)
+
+        def deliver():
+            self._exchange(b, count)
+            if mine >= 0:
+                self._assemble(b, colorize_fn, mine)
+
+        if not self.on_gpu:
+            render_all()
+            deliver()
+        else:
+            if self._used[b]:
+                self.compute.wait_event(self.delivered[b])     # the slot's send buffers are free again
+            with torch.cuda.stream(self.compute):
+                render_all()
+                self.rendered[b].record(self.compute)
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(self.rendered[b])
+                deliver()
+                self.delivered[b].record(self.comm)
+            self._used[b] = True
+        self.frame_index[b] = mine
+        return b
+
+    def prime(self) -> None:
+        """Open every pairwise connection (RCCL sets up a peer connection on first use) before timing."""
+        if self.world == 1:
+            return
+        dev = self.device if not self.stage else torch.device("cpu")
+        tx = torch.zeros(self.world, 16, device=dev)
+        rx = torch.zeros(self.world, 16, device=dev)
+        ops = []
+        for r in range(self.world):
+            if r != self.rank:
+                ops.append(dist.P2POp(dist.isend, tx[r], r, self.group))
+                ops.append(dist.P2POp(dist.irecv, rx[r], r, self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if self.on_gpu:
+            torch.cuda.synchronize(self.device)
+
+    def wait(self, slot: int) -> None:
+        if self.on_gpu and self._used[slot]:
+            self.delivered[slot].synchronize()
+
+    def drain(self) -> None:
+        if self.on_gpu:
+            self.compute.synchronize()
+            self.comm.synchronize()

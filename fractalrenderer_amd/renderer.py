@@ -179,6 +179,26 @@ class Renderer:
         p = state.to_params(fractal_type, precision)
         return self._lib.fr_render_frame_png(self._ctx, C.byref(p), width, height, os.fsencode(path)) == _capi.FR_OK
 
+    @staticmethod
+    def colorize_supported(state: FractalState, fractal_type: FractalType = FractalType.Mandelbrot,
+                           precision: Precision = Precision.F64) -> bool:
+        """fr_colorize_supported: the colour plane is a function of the smooth-count plane alone."""
+        p = state.to_params(fractal_type, precision)
+        return bool(_capi.lib().fr_colorize_supported(C.byref(p)))
+
+    def colorize(self, state: FractalState, nu, rgba, *, fractal_type: FractalType = FractalType.Mandelbrot,
+                 precision: Precision = Precision.F64, post_chain: bool = False,
+                 stream: Optional[int] = None) -> None:
+        """fr_colorize_async: device nu plane (float64 for F64, float32 for F32) -> device RGBA f32 plane,
+        bit-identical to the rgba plane render() writes.  Enqueued on `stream` (raw hipStream_t), no sync."""
+        p = state.to_params(fractal_type, precision, post_chain)
+        n = nu.numel()
+        p_nu, k1 = self._ptr(nu, "float64" if precision == Precision.F64 else "float32", n, "nu")
+        p_rgba, k2 = self._ptr(rgba, "float32", n * 4, "rgba")
+        if k1 != "device" or k2 != "device":
+            raise ValueError("colorize needs device tensors")
+        _capi.check(self._lib.fr_colorize_async(self._ctx, C.byref(p), n, p_nu, p_rgba, C.c_void_p(stream or 0)))
+
     def export_rgb16(self, rgba, width: int, height: int, out=None, through_half: bool = False):
         """16-bit export of export_print_quality (src/vk_engine.cpp:2054-2073): clamp, *65535, flip."""
         p_in, kind_in = self._ptr(rgba, "float32", width * height * 4, "rgba")

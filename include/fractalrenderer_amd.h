@@ -228,6 +228,23 @@ int fr_ctx_last_grid(fr_ctx* ctx);
 /* Number of compute units of the context's device (hipDeviceProp_t.multiProcessorCount). */
 int fr_ctx_compute_units(fr_ctx* ctx);
 
+/* ---- recolour from the smooth-count plane (multi-GPU exchange payload) ------------------------
+ * New design, no reference counterpart (the reference is single-GPU): for the plain colourings the
+ * shaders' colour is a function of the smooth count alone (shaders/mandelbrot.comp:179-190,
+ * shaders/julia.comp:243-248, shaders/burning_ship.comp:296-299), so the ranks of a row-band sharded
+ * frame can ship the 8-byte (fp64) / 4-byte (fp32) nu plane over xGMI instead of the 16-byte colour
+ * and the destination recolours it, bit-identically to what the render kernels write.
+ *
+ * fr_colorize_supported: 1 when that holds for `params` (Mandelbrot / JuliaSet / BurningShip, no
+ * trap / stripe / interior-style variant, antialiasing_samples <= 1, bailout large enough that
+ * nu == max_iterations identifies exactly the interior samples), else 0.
+ * fr_colorize_async: nu (n_pixels doubles for FR_PRECISION_F64, floats for F32) -> rgba (n_pixels x
+ * RGBA f32), both device pointers, enqueued on hip_stream (NULL: the context's stream), no host sync;
+ * FR_FLAG_POST_CHAIN applies the post chain as fr_render does.  FR_ERR_UNSUPPORTED when not supported. */
+int fr_colorize_supported(const fr_params* params);
+int fr_colorize_async(fr_ctx* ctx, const fr_params* params, uint64_t n_pixels, const void* nu, float* rgba,
+                      void* hip_stream);
+
 /* ---- 8-bit export (reference a9) ------------------------------------------------------ */
 
 /* The CPU loop of VulkanEngine::render_animation_frame, src/vk_engine.cpp:1344-1371, on the

@@ -322,6 +322,17 @@ static float* deep_zoom_orbit(const fro_params* P, int32_t* len_out)
     return f;
 }
 
+/* restatement of the colour stage alone, for checking fr_colorize_async and the multi-GPU exchange */
+void fro_colorize(const fro_params* p, int64_t n, const double* nu, float* rgba)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float rgb[3];
+        if (p->precision == 1) colour_of_nu_f64(p, nu[i], rgb);
+        else colour_of_nu_f32(p, (float)nu[i], rgb);
+        rgba[4 * i + 0] = rgb[0]; rgba[4 * i + 1] = rgb[1]; rgba[4 * i + 2] = rgb[2]; rgba[4 * i + 3] = 1.0f;
+    }
+}
+
 int32_t fro_max_threads(void)
 {
 #ifdef _OPENMP

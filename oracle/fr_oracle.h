@@ -91,6 +91,11 @@ int32_t fro_reference_orbit(double cx, double cy, int32_t max_iter, double* out_
 void fro_export_rgb8(const float* rgba, int32_t W, int32_t H, uint8_t* rgb8,
                      int32_t through_half);
 
+/* Colour stage alone: nu (as fro_render_rows returns it: doubles, fp32 values widened exactly) -> RGBA f32,
+ * for the plain colourings whose colour is a function of nu (see include/fractalrenderer_amd.h,
+ * fr_colorize_supported).  Applies the post chain when p->post_chain. */
+void fro_colorize(const fro_params* p, int64_t n, const double* nu, float* rgba);
+
 int32_t fro_max_threads(void);
 
 #ifdef __cplusplus

@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
         L.fro_reference_orbit.restype = C.c_int32
         L.fro_reference_orbit.argtypes = [C.c_double, C.c_double, C.c_int32, C.c_void_p]
         L.fro_export_rgb8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        L.fro_colorize.argtypes = [C.POINTER(_FroParams), C.c_int64, C.c_void_p, C.c_void_p]
+        L.fro_colorize.restype = None
         L.fro_max_threads.restype = C.c_int32
         _lib = L
     return _lib
@@ -161,6 +163,15 @@ def export_rgb8(rgba: np.ndarray, through_half: bool = False) -> np.ndarray:
     src = np.ascontiguousarray(rgba, np.float32)
     out = np.empty((H, W, 3), np.uint8)
     lib().fro_export_rgb8(src.ctypes.data, W, H, out.ctypes.data, int(through_half))
+    return out
+
+
+def colorize(p: "OracleParams", nu: np.ndarray) -> np.ndarray:
+    """Colour stage alone (fro_colorize): nu plane -> (..., 4) float32 RGBA."""
+    src = np.ascontiguousarray(nu, np.float64)
+    out = np.empty(src.shape + (4,), np.float32)
+    cp = p.to_c()
+    lib().fro_colorize(C.byref(cp), src.size, src.ctypes.data, out.ctypes.data)
     return out
 
 

@@ -484,3 +484,145 @@ def test_export_rgb16(fr, renderer, oracle):
     half = renderer.export_rgb16(rgba, W, H, through_half=True)
     want_h = (np.clip(rgba[::-1, :, :3].astype(np.float16).astype(np.float32), 0.0, 1.0) * np.float32(65535.0)).astype(np.uint16)
     assert np.array_equal(half, want_h)
+
+
+@pytest.mark.parametrize("name", sorted(n for n, (p, _, _) in CASES.items()
+                                         if p.fractal <= 2 and p.aa <= 1 and not needs_effects(p)))
+def test_colorize_reproduces_the_rendered_colour(fr, renderer, oracle, name):
+    """fr_colorize_async: the colour plane recomputed from the nu plane is BIT-identical to the one the
+    render kernels write (the multi-GPU exchange ships nu and recolours at the destination)."""
+    import torch
+    p, W, H = CASES[name]
+    st = to_state(fr, p)
+    ftype, prec = fr.FractalType(p.fractal), (fr.Precision.F64 if p.precision == 1 else fr.Precision.F32)
+    supported = renderer.colorize_supported(st, ftype, prec)
+    assert supported == ((p.bailout >= 2.5) if p.fractal == 0 else (p.bailout >= 1.25))
+    dev = torch.device("cuda:0")
+    for post in (False, True):
+        rgba = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+        nu = torch.empty((H, W), dtype=torch.float64 if p.precision == 1 else torch.float32, device=dev)
+        renderer.render(st, W, H, fractal_type=ftype, precision=prec, post_chain=post, rgba=rgba, nu=nu)
+        again = torch.full_like(rgba, -1.0)
+        if not supported:
+            with pytest.raises(fr.FractalRendererError) as e:
+                renderer.colorize(st, nu, again, fractal_type=ftype, precision=prec, post_chain=post)
+            assert e.value.status == fr._capi.FR_ERR_UNSUPPORTED
+            continue
+        renderer.colorize(st, nu, again, fractal_type=ftype, precision=prec, post_chain=post)
+        torch.cuda.synchronize()
+        assert torch.equal(again, rgba)
+        if not post:
+            ref = oracle.colorize(p, nu.cpu().numpy().astype(np.float64))
+            assert np.abs(again.cpu().numpy() - ref).max() <= RGB_TOL
+
+
+def test_colorize_rejects_effect_colourings(fr, renderer):
+    st = fr.FractalState(orbit_trap_enabled=True)
+    assert not renderer.colorize_supported(st)
+    assert not renderer.colorize_supported(fr.FractalState(antialiasing_samples=2))
+    assert not renderer.colorize_supported(fr.FractalState(), fr.FractalType.Deep_Zoom, fr.Precision.F32)
+    assert not renderer.colorize_supported(fr.FractalState(interior_style=3), fr.FractalType.BurningShip)
+    assert renderer.colorize_supported(fr.FractalState(interior_style=1))
+
+
+def test_frame_exchange_single_rank_on_gpu(fr, renderer, oracle):
+    """world 1 (no process group): FrameExchange degenerates to render -> assemble -> recolour on two
+    streams; exercises the slot reuse events of the pipelined path."""
+    import torch
+    from fractalrenderer_amd.distributed import FrameExchange
+    W, H = 160, 96
+    dev = torch.device("cuda:0")
+    states = [fr.FractalState(max_iterations=64 + 32 * k, palette_mode=k % 6) for k in range(5)]
+    for payload in ("nu", "rgba"):
+        fx = FrameExchange(W, H, payload=payload, device=dev, rows_per_strip=8)
+
+        def render_fn(shard, out, frame, plane):
+            kw = {"nu": out} if plane == "nu" else {"rgba": out}
+            renderer.render(states[frame], W, H, shard=shard, sync=False,
+                            stream=torch.cuda.current_stream().cuda_stream, **kw)
+
+        def colorize_fn(nu_frame, rgba_frame, frame):
+            renderer.colorize(states[frame], nu_frame, rgba_frame, stream=torch.cuda.current_stream().cuda_stream)
+
+        for k in range(5):
+            slot = fx.submit_group(render_fn, k, 1, colorize_fn if payload == "nu" else None)
+            fx.wait(slot)
+            assert fx.frame_index[slot] == k
+            ref = oracle.render(oracle.OracleParams(max_iterations=64 + 32 * k, palette_mode=k % 6), W, H)
+            assert np.abs(fx.frame_rgba[slot].cpu().numpy() - ref.rgba).max() <= RGB_TOL
+            if payload == "nu":
+                assert np.abs(fx.frame_nu[slot].cpu().numpy() - ref.nu).max() <= NU_TOL_F64
+        fx.drain()
+
+
+def _fx_gpu_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fractalrenderer_amd as fr
+        from fractalrenderer_amd.distributed import FrameExchange
+        W, H, nframes = 256, 192, 5
+        dev = torch.device("cuda:0")
+        r = fr.Renderer(0)
+        states = [fr.FractalState(max_iterations=200 + 40 * k, zoom=3.0 - 0.2 * k) for k in range(nframes)]
+        fx = FrameExchange(W, H, payload="nu", device=dev)          # gloo -> strips bounce through pinned host memory
+        assert fx.stage
+
+        def render_fn(shard, out, frame, plane):
+            r.render(states[frame], W, H, shard=shard, sync=False, nu=out, stream=torch.cuda.current_stream().cuda_stream)
+
+        def colorize_fn(nu_frame, rgba_frame, frame):
+            r.colorize(states[frame], nu_frame, rgba_frame, stream=torch.cuda.current_stream().cuda_stream)
+
+        fx.prime()
+        ok, f = True, 0
+        whole_rgba = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+        whole_nu = torch.empty((H, W), dtype=torch.float64, device=dev)
+        pending = []
+        while f < nframes:
+            count = min(world, nframes - f)
+            slot = fx.submit_group(render_fn, f, count, colorize_fn)        # pipelined: no drain between groups
+            pending.append((slot, f + rank if rank < count else -1))
+            if len(pending) == 2:
+                s0, fi = pending.pop(0)
+                fx.wait(s0)
+                if fi >= 0:
+                    r.render(states[fi], W, H, rgba=whole_rgba, nu=whole_nu)
+                    ok = ok and torch.equal(fx.frame_rgba[s0], whole_rgba) and torch.equal(fx.frame_nu[s0], whole_nu)
+            f += count
+        fx.drain()
+        for s0, fi in pending:
+            if fi >= 0:
+                r.render(states[fi], W, H, rgba=whole_rgba, nu=whole_nu)
+                ok = ok and torch.equal(fx.frame_rgba[s0], whole_rgba) and torch.equal(fx.frame_nu[s0], whole_nu)
+        r.close()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_exchange_two_ranks_sharing_the_card(fr):
+    """Rehearsal of the N > 1 GPU path on ONE card: 2 processes, gloo rendezvous, strips bounced through
+    pinned host memory (RCCL refuses two ranks on one device).  Every frame delivered to rank
+    (frame mod 2) must equal, bitwise, a whole-frame render of the same state."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fx_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for _ in range(2):
+        rank, ok = q.get(timeout=5)
+        assert ok, rank
