@@ -117,6 +117,8 @@ def main() -> None:
     ap.add_argument("--rows-per-strip", type=int, default=0)
     ap.add_argument("--payload", default="auto", choices=["auto", "nu", "rgba"],
                     help="N > 1: plane shipped over xGMI (auto: nu when the colour is a function of nu)")
+    ap.add_argument("--render-lanes", type=int, default=0,
+                    help="N > 1: concurrent render contexts/streams per rank (0: min(4, N))")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsals only: gloo + --same-device on one card")
     ap.add_argument("--same-device", action="store_true", help="rehearsals only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -195,12 +197,18 @@ def main() -> None:
         if payload == "auto":
             payload = "nu" if r.colorize_supported(state, ftype, prec) else "rgba"
         nu_dtype = torch.float64 if prec == fr.Precision.F64 else torch.float32
-        fx = FrameExchange(W, H, payload=payload, nu_dtype=nu_dtype, device=dev, rows_per_strip=args.rows_per_strip)
+        lanes = args.render_lanes or min(4, world)
+        fx = FrameExchange(W, H, payload=payload, nu_dtype=nu_dtype, device=dev, rows_per_strip=args.rows_per_strip,
+                           render_lanes=lanes)
+        # one render context per lane: a context is not re-entrant, distinct contexts run concurrently
+        ctxs = [r] + [fr.Renderer(local_rank) for _ in range(lanes - 1)]
+        for c in ctxs[1:]:
+            c.set_tuning(args.wg_per_cu, args.run_max, args.shape)
 
-        def render_fn(shard, out, _frame, plane):
+        def render_fn(shard, out, _frame, plane, lane=0):
             kw = {"nu": out} if plane == "nu" else {"rgba": out}
-            r.render(state, W, H, fractal_type=ftype, precision=prec, shard=shard, sync=False,
-                     stream=torch.cuda.current_stream().cuda_stream, **kw)
+            ctxs[lane].render(state, W, H, fractal_type=ftype, precision=prec, shard=shard, sync=False,
+                              stream=torch.cuda.current_stream().cuda_stream, **kw)
 
         def colorize_fn(nu_frame, rgba_frame, _frame):
             r.colorize(state, nu_frame, rgba_frame, fractal_type=ftype, precision=prec,
@@ -242,7 +250,8 @@ def main() -> None:
                        "parallelism": (f"row strips of {fx.R} rows round-robin over {world} GPUs; frames in groups of {world}, "
                                        f"frame g*{world}+j gathered to rank j by one RCCL all-to-all per group "
                                        f"(payload: {payload} plane, {'recoloured at the destination, ' if payload == 'nu' else ''}"
-                                       "double-buffered)" if world > 1 else "1 GPU, persistent tile queue"),
+                                       f"double-buffered, {lanes} concurrent render contexts per rank)" if world > 1
+                                       else "1 GPU, persistent tile queue"),
                        "compute_units": r.compute_units},
         }
         if world == 1:
@@ -262,6 +271,9 @@ def main() -> None:
                 out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)
 
+    if world > 1:
+        for c in ctxs[1:]:
+            c.close()
     r.close()
     if world > 1:
         dist.destroy_process_group()

@@ -122,6 +122,28 @@ class FractalRendererError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64 (SONAME
+    libamdhip64.so.7, the same as /opt/rocm's, but requested by torch under the name libamdhip64.so).  If
+    this library is loaded BEFORE torch it binds /opt/rocm's copy, torch then loads its own next to it, and
+    the second runtime to initialise finds no device ("No HIP GPUs are available").  Loading torch's copy
+    first -- by path, without importing torch -- makes both bind the same runtime whatever the import
+    order.  Without an installed torch this is a no-op and the library uses /opt/rocm's runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for loc in (spec.submodule_search_locations or []) if spec else []:
+        cand = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return
+
+
 def lib() -> C.CDLL:
     """Load the C-ABI library.  Raises (never falls back) if it has not been built."""
     global _lib
@@ -130,6 +152,7 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C fractalrenderer_amd/csrc`. There is no Python/CPU fallback for the render path.")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol

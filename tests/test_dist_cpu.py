@@ -86,7 +86,7 @@ def _fx_worker(rank, world, port, W, H, R, payload, nframes, q):
         fx = FrameExchange(W, H, payload=payload, nu_dtype=torch.float64, device=torch.device("cpu"), rows_per_strip=R)
         params = lambda f: O.OracleParams(max_iterations=48 + 16 * f, palette_mode=f % 6, center_x=-0.5 - 0.01 * f)  # noqa: E731
 
-        def render_fn(shard, out, frame, plane):
+        def render_fn(shard, out, frame, plane, lane=0):
             assert plane == payload
             rows = shard.global_rows(H)
             assert out.shape[0] == len(rows)

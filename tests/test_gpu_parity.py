@@ -503,6 +503,7 @@ def test_colorize_reproduces_the_rendered_colour(fr, renderer, oracle, name):
         nu = torch.empty((H, W), dtype=torch.float64 if p.precision == 1 else torch.float32, device=dev)
         renderer.render(st, W, H, fractal_type=ftype, precision=prec, post_chain=post, rgba=rgba, nu=nu)
         again = torch.full_like(rgba, -1.0)
+        torch.cuda.synchronize()        # the fill ran on torch's stream, colorize runs on the context's own
         if not supported:
             with pytest.raises(fr.FractalRendererError) as e:
                 renderer.colorize(st, nu, again, fractal_type=ftype, precision=prec, post_chain=post)
@@ -536,7 +537,7 @@ def test_frame_exchange_single_rank_on_gpu(fr, renderer, oracle):
     for payload in ("nu", "rgba"):
         fx = FrameExchange(W, H, payload=payload, device=dev, rows_per_strip=8)
 
-        def render_fn(shard, out, frame, plane):
+        def render_fn(shard, out, frame, plane, lane=0):
             kw = {"nu": out} if plane == "nu" else {"rgba": out}
             renderer.render(states[frame], W, H, shard=shard, sync=False,
                             stream=torch.cuda.current_stream().cuda_stream, **kw)
@@ -571,12 +572,14 @@ def _fx_gpu_worker(rank, world, port, q):
         W, H, nframes = 256, 192, 5
         dev = torch.device("cuda:0")
         r = fr.Renderer(0)
+        r2 = fr.Renderer(0)                                          # second render context for lane 1
         states = [fr.FractalState(max_iterations=200 + 40 * k, zoom=3.0 - 0.2 * k) for k in range(nframes)]
-        fx = FrameExchange(W, H, payload="nu", device=dev)          # gloo -> strips bounce through pinned host memory
+        fx = FrameExchange(W, H, payload="nu", device=dev, render_lanes=2)   # gloo -> strips bounce through pinned host memory
         assert fx.stage
 
-        def render_fn(shard, out, frame, plane):
-            r.render(states[frame], W, H, shard=shard, sync=False, nu=out, stream=torch.cuda.current_stream().cuda_stream)
+        def render_fn(shard, out, frame, plane, lane=0):
+            (r, r2)[lane].render(states[frame], W, H, shard=shard, sync=False, nu=out,
+                                 stream=torch.cuda.current_stream().cuda_stream)
 
         def colorize_fn(nu_frame, rgba_frame, frame):
             r.colorize(states[frame], nu_frame, rgba_frame, stream=torch.cuda.current_stream().cuda_stream)
@@ -602,6 +605,7 @@ def _fx_gpu_worker(rank, world, port, q):
             if fi >= 0:
                 r.render(states[fi], W, H, rgba=whole_rgba, nu=whole_nu)
                 ok = ok and torch.equal(fx.frame_rgba[s0], whole_rgba) and torch.equal(fx.frame_nu[s0], whole_nu)
+        r2.close()
         r.close()
         q.put((rank, ok))
     finally:
@@ -626,3 +630,23 @@ def test_frame_exchange_two_ranks_sharing_the_card(fr):
     for _ in range(2):
         rank, ok = q.get(timeout=5)
         assert ok, rank
+
+
+def test_library_first_then_torch_share_one_hip_runtime():
+    """Import order must not matter: the library loaded (and a context created) BEFORE torch is imported
+    must leave torch able to see the GPU, and torch memory usable by the library."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import fractalrenderer_amd as fr\n"
+            "assert 'torch' not in sys.modules\n"
+            "r = fr.Renderer(0)\n"
+            "import torch\n"
+            "nu = torch.zeros((64, 64), dtype=torch.float64, device='cuda:0')\n"
+            "r.render(fr.FractalState(), 64, 64, nu=nu)\n"
+            "assert float(nu.max()) == 256.0 and float(nu.min()) > 0.0\n"
+            "r.close(); print('ok')\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
