@@ -51,6 +51,8 @@ struct fr_ctx {
     uint32_t tune_run_min;      /* 0 = automatic */
     int tune_shift_bias;        /* added to the guided-run shift */
     uint32_t tune_queue_flags;  /* 0 = automatic, else 0x100 | flags */
+    uint32_t tune_probes;       /* tile pass: shards a wave probes before exiting (0 = automatic) */
+    uint32_t tune_stream_probes;/* same for the stream / lane-pool passes */
     uint64_t* diag;             /* optional device buffer for per-wave timelines */
     uint32_t last_grid;
     uint32_t tune_shape;        /* 0 = automatic, else FPW_LOG2 (3, 4, 6) */
@@ -176,6 +178,10 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         c->diag_stride = (size_t)value;               /* u64 words between the diag regions of consecutive stages */
     } else if (!strcmp(name, "queue_flags")) {
         c->tune_queue_flags = (uint32_t)value;         /* 0 = automatic; else 0x100 | kQueueScatter | kQueuePrefetch */
+    } else if (!strcmp(name, "probes")) {
+        c->tune_probes = (uint32_t)value & 0xFu;
+    } else if (!strcmp(name, "stream_probes")) {
+        c->tune_stream_probes = (uint32_t)value & 0xFu;
     } else if (!strcmp(name, "diag_buffer")) {
         c->diag = (uint64_t*)(uintptr_t)value;        /* device pointer, 4 x u64 per wave of the grid; 0 = off */
     } else {
@@ -539,7 +545,17 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     }
     if (tq.run_min > tq.run_max) tq.run_min = tq.run_max;
     /* no claim-ahead by default: measured equal or better without it on every workload */
-    tq.flags = c->tune_queue_flags ? (c->tune_queue_flags & 0xFFu) : 0u;
+    tq.flags = c->tune_queue_flags ? (c->tune_queue_flags & 0x0Fu) : 0u;
+    /* Staged tile pass: sub-tiles are dealt evenly to the shards and cost at most b0 iterations each, so a
+     * wave whose home shard is dry exits instead of probing the other 7 (measured: the exit storm of
+     * 4096 waves x 8 serialized atomics costs 31 us of the 260 us tile pass of C2 and 36 of the 74 us of
+     * a 1/8 shard, profiles/r01_probe_limit.txt).  Unstaged passes keep full stealing: their items cost
+     * anything between 1 and max_iter iterations. */
+    {
+        uint32_t probes = c->tune_probes ? c->tune_probes : ((staged && grid >= 64u) ? 1u : 0u);
+        if (grid < (uint32_t)kShards) probes = 0;          /* fewer workgroups than shards: everybody probes everything */
+        tq.flags |= probes << kQueueProbeShift;
+    }
     c->last_grid = grid;
 
     /* ---- survivor streams (ping-pong) in context scratch ------------------------------------------ */
@@ -622,7 +638,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 16u;
         a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 2u;
         if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
-        a.q.flags = tq.flags & kQueuePrefetch;
+        a.q.flags = (tq.flags & kQueuePrefetch) | (c->tune_stream_probes << kQueueProbeShift);
         a.diag = c->diag ? c->diag + (size_t)k * c->diag_stride : nullptr;
         if (pool_stream) {
             a.i0 = bounds[0];

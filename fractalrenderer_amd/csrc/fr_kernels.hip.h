@@ -52,6 +52,7 @@ constexpr int kShardBlock = 16;          /* sub-tiles are dealt to shards in blo
 constexpr int kFastBlock = 16;           /* iterations per unchecked block                 */
 constexpr uint32_t kQueueScatter = 1u;   /* bit-reversed block order                       */
 constexpr uint32_t kQueuePrefetch = 2u;  /* issue the next dequeue before iterating the current run */
+constexpr uint32_t kQueueProbeShift = 4; /* bits 4-7: shards a wave may probe before giving up (0 = all 8) */
 constexpr uint32_t kInvalidPixel = 0xFFFFFFFFu;
 constexpr int kRingSlots = 128;          /* survivor ring capacity per wave (records)      */
 
@@ -381,7 +382,7 @@ struct WaveQueue {
     uint32_t len_cap;
     uint32_t run_shift, run_min, run_max;
     uint32_t lane;
-    uint32_t shard, tried, seen;
+    uint32_t shard, tried, seen, max_tries;
     uint32_t cur_n, cur_raw, next_n, next_raw;
     bool prefetch, started, pending;
 
@@ -413,7 +414,7 @@ struct WaveQueue {
         heads = h;
         n_groups = groups; group = group_items; len_words = nullptr; len_cap = 0;
         run_shift = shift; run_min = rmin; run_max = rmax; prefetch = pf; lane = ln;
-        shard = xcc_id(); tried = 0; seen = 0;
+        shard = xcc_id(); tried = 0; seen = 0; max_tries = (uint32_t)kShards;
         cur_n = cur_raw = next_n = next_raw = 0;
         started = false; pending = false;
     }
@@ -423,6 +424,19 @@ struct WaveQueue {
         init(h, 0, 1, shift, rmin, rmax, pf, ln);
         len_words = lengths; len_cap = cap;
     }
+    /* Probing every other shard before exiting costs up to 8 dependent atomics per wave, and all waves of
+     * a launch do it at the same moment (waves x 8 serialized RMWs on 8 words); a launch whose items are
+     * dealt evenly and cost about the same can stop after its home shard (+ a neighbour). */
+    __device__ __forceinline__ void set_probes(uint32_t flags)
+    {
+        const uint32_t p = (flags >> kQueueProbeShift) & 0xFu;
+        if (p == 0u || p >= (uint32_t)kShards) return;
+        max_tries = p;
+        /* with limited probing every shard must be SOMEBODY's home whatever the hardware's workgroup ->
+         * XCD placement is: take the home from the workgroup index (identical to the XCD id under the
+         * usual round-robin dispatch).  The host only limits probing on grids of >= 64 workgroups. */
+        shard = blockIdx.x & (uint32_t)(kShards - 1);
+    }
     /* hands out the next run [begin, begin+count) of shard `sh`; false = no work left anywhere */
     __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& count, uint32_t& sh)
     {
@@ -430,7 +444,7 @@ struct WaveQueue {
         else {
             /* shards known to be empty cost no atomic (a follow-up pass may have nothing to do) */
             while (shard_len(shard) == 0u) {
-                if (++tried >= (uint32_t)kShards) return false;
+                if (++tried >= max_tries) return false;
                 shard = (shard + 1u) & (uint32_t)(kShards - 1);
                 seen = 0;
             }
@@ -443,7 +457,7 @@ struct WaveQueue {
             const uint32_t l = shard_len(shard);
             if (b >= l) {
                 do {
-                    if (++tried >= (uint32_t)kShards) return false;
+                    if (++tried >= max_tries) return false;
                     shard = (shard + 1u) & (uint32_t)(kShards - 1);
                 } while (shard_len(shard) == 0u);
                 seen = 0;
@@ -764,6 +778,7 @@ tile_kernel(const LaunchArgs A)
     WaveQueue q;
     q.init(A.q.heads, A.q.n_blk_padded, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max,
            (A.q.flags & kQueuePrefetch) != 0, (uint32_t)lane);
+    q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
     uint32_t diag_items = 0, diag_claims = 0;
@@ -1003,6 +1018,7 @@ stream_kernel(const LaunchArgs A)
     WaveQueue q;
     q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max,
                    (A.q.flags & kQueuePrefetch) != 0, lane);
+    q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
     uint32_t diag_items = 0, diag_claims = 0;
@@ -1151,6 +1167,7 @@ pool_kernel(const LaunchArgs A)
     else
         q.init(A.q.heads, A.q.n_blk_padded, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max,
                (A.q.flags & kQueuePrefetch) != 0, lane);
+    q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
     uint32_t diag_items = 0, diag_claims = 0;

@@ -209,11 +209,13 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "staging"            3 = tile pass for the first "stage_first" iterations + ONE lane-pool pass over the
  *                        compacted survivors to max_iter, 2 = tile pass + block stream passes, 1 = single pass,
  *                        0 = automatic (= 3 wherever it applies: no SSAA, no trap/stripe effects)
- *   "stage_first"        iteration budget of the tile pass (default 32)
+ *   "stage_first"        iteration budget of the tile pass (default ~max_iter/48 within [32, 128])
  *   "stage_ratio"        budget growth per stream pass (default 4)
  *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue may claim in a stream pass
  *   "stream_workgroups_per_cu"          workgroups per compute unit of the stream pass
  *   "queue_flags"        0x100 | 1 (bit-reversed tile order) | 2 (prefetch the next dequeue)
+ *   "probes", "stream_probes"  queue shards a wave tries before it exits, tile pass / stream passes
+ *                        (1..8; 0 = automatic: 1 for a staged tile pass, 8 otherwise)
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1
  *   "diag_buffer"        device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks,
  *                        items processed, dequeues); 0 disables.  "diag_stride" = uint64 words

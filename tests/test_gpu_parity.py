@@ -168,7 +168,8 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
     p, W, H = CASES["seahorse_0008_f64"]
     base = gpu_render(fr, renderer, p, 200, 120)
     assert renderer.last_stages() == 2                     # default: tile pass + lane-pool pass
-    opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "queue_flags", "stream_workgroups_per_cu", "pool_refill_at", "pool_passes", "pool_evict_at")
+    opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "queue_flags", "stream_workgroups_per_cu", "pool_refill_at", "pool_passes", "pool_evict_at",
+            "probes", "stream_probes")
     try:
         for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
             renderer.set_tuning(wg, run, shape)
@@ -179,6 +180,8 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
         for kw in (dict(staging=1), dict(staging=2), dict(staging=2, stage_first=16), dict(staging=2, stage_first=64, stage_ratio=2),
                    dict(staging=2, stage_ratio=16), dict(staging=2, stage_first=512), dict(staging=2, stream_run_max=1),
                    dict(queue_flags=0x100), dict(queue_flags=0x103), dict(staging=2, queue_flags=0x103),
+                   dict(probes=8), dict(probes=2), dict(probes=1, stream_probes=1), dict(staging=1, probes=1),
+                   dict(staging=2, probes=3, stream_probes=2),
                    dict(staging=2, stage_first=16, stage_ratio=2, queue_flags=0x101, stream_workgroups_per_cu=2),
                    dict(staging=3), dict(staging=3, stage_first=64, pool_refill_at=8), dict(staging=3, stage_first=16, pool_refill_at=64),
                    dict(staging=3, stream_run_max=1, stream_workgroups_per_cu=1), dict(staging=3, pool_passes=1),
@@ -650,3 +653,21 @@ def test_library_first_then_torch_share_one_hip_runtime():
             "r.close(); print('ok')\n") % root
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (8, 8), (64, 8), (100, 37), (520, 16)])
+def test_limited_probing_on_small_grids(fr, renderer, oracle, W, H):
+    """Waves that stop after their home shard (probes=1) must still cover every shard, whatever the grid
+    size: grids smaller than the shard count fall back to full probing, larger ones take the home shard
+    from the workgroup index."""
+    p = oracle.OracleParams(max_iterations=200, center_x=-0.75, zoom=2.0)
+    ref = oracle.render(p, W, H)
+    try:
+        for probes, wg in ((1, 0), (2, 0), (1, 1)):
+            renderer.set_option("probes", probes)
+            renderer.set_tuning(wg, 0, 0)
+            rgba, nu, it = gpu_render(fr, renderer, p, W, H)
+            check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
+    finally:
+        renderer.set_option("probes", 0)
+        renderer.set_tuning()

@@ -14,6 +14,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--max-iter", type=int, default=1024)
+    ap.add_argument("--opt", action="append", default=[], help="name=value passed to fr_ctx_set_option on every context")
+    ap.add_argument("--only", type=int, default=0, help="only this N")
     args = ap.parse_args()
     import torch
     import fractalrenderer_amd as fr
@@ -24,6 +26,10 @@ def main():
     nctx = 4
     rs = [fr.Renderer(0) for _ in range(nctx)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nctx)]
+    for o in args.opt:
+        k, v = o.split("=")
+        for r_ in rs:
+            r_.set_option(k, int(v))
 
     cur = torch.cuda.Stream(device=dev)     # a real stream: handle 0 would mean "the context's own stream"
 
@@ -42,7 +48,7 @@ def main():
     full = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
     base = timed(lambda: rs[0].render(st, W, H, rgba=full, sync=False, stream=cur.cuda_stream))
     print("1 GPU whole frame rgba: %.3f ms" % base)
-    for N in (1, 2, 4, 8):
+    for N in ((args.only,) if args.only else (1, 2, 4, 8)):
         R = pick_rows_per_strip(H, N)
         sh = fr.Shard(0, N, R)
         rows = sh.rows(H)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave timeline of one render from the kernels' diag buffer, per stage: when waves start/finish,
-how the work and the dequeues are spread.  usage: timeline.py workload [max_iter] [opt=value ...]"""
+how the work and the dequeues are spread.
+usage: timeline.py workload [max_iter] [opt=value ...] [nparts=N (part 0 of a sharded frame)] [plane=nu|rgba]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,10 +16,18 @@ if args and args[0].isdigit():
     st["max_iterations"] = int(args[0]); args = args[1:]
 W, H = w["W"], w["H"]
 r = fr.Renderer(0)
-for a in args:
-    k, v = a.split("="); r.set_option(k, int(v, 0))
-rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
-kw = dict(fractal_type=fr.FractalType[w["fractal"]], precision=fr.Precision[w["precision"]], rgba=rgba)
+nparts, plane = 1, "rgba"
+for a in list(args):
+    k, v = a.split("=")
+    if k == "nparts": nparts = int(v); args.remove(a)
+    elif k == "plane": plane = v; args.remove(a)
+    else: r.set_option(k, int(v, 0))
+from fractalrenderer_amd.distributed import pick_rows_per_strip
+shard = fr.Shard(0, nparts, pick_rows_per_strip(H, nparts)) if nparts > 1 else None
+rows = shard.rows(H) if shard else H
+out = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda:0") if plane == "rgba" else \
+    torch.empty((rows, W), dtype=torch.float64 if w["precision"] == "F64" else torch.float32, device="cuda:0")
+kw = dict(fractal_type=fr.FractalType[w["fractal"]], precision=fr.Precision[w["precision"]], shard=shard, **{plane: out})
 state = fr.FractalState(**st)
 for _ in range(3):
     r.render(state, W, H, **kw)
@@ -44,5 +53,10 @@ for s in range(nst):
     edges = np.linspace(lo, hi, 11)
     live = [(np.minimum(end, b) - np.maximum(start, a)).clip(min=0).sum() / max(b - a, 1e-9) for a, b in zip(edges[:-1], edges[1:])]
     worked = items > 0
+    if worked.sum() > 8 and np.ptp(items[worked]) > 0:
+        dur = (end - start)[worked]
+        A = np.vstack([np.ones(worked.sum()), items[worked], claims[worked]]).T
+        coef = np.linalg.lstsq(A, dur, rcond=None)[0]
+        print(f"           wave time ~ {coef[0]:.1f} us + {coef[1]:.2f} us/item + {coef[2]:.2f} us/dequeue  (start spread {np.percentile(start,99)-lo:.1f} us)")
     print(f"  stage {s}: {lo:8.1f} -> {hi:8.1f} us ({hi-lo:7.1f}), waves {ran.sum()} ({worked.sum()} with work), items/wave mean {items[worked].mean() if worked.any() else 0:.1f} "
           f"max {items.max()}, dequeues {claims.sum()}, finish p50 {np.percentile(end,50)-lo:.1f} p99 {np.percentile(end,99)-lo:.1f}; live/10%: " + " ".join(f"{x:.0f}" for x in live))
