@@ -53,6 +53,7 @@ struct fr_ctx {
     uint32_t tune_queue_flags;  /* 0 = automatic, else 0x100 | flags */
     uint32_t tune_probes;       /* tile pass: shards a wave probes before exiting (0 = automatic) */
     uint32_t tune_stream_probes;/* same for the stream / lane-pool passes */
+    uint32_t tune_stream_rotate;/* 0 automatic, 1 regions by XCD, 2 writers rotate over the regions */
     uint64_t* diag;             /* optional device buffer for per-wave timelines */
     uint32_t last_grid;
     uint32_t tune_shape;        /* 0 = automatic, else FPW_LOG2 (3, 4, 6) */
@@ -182,6 +183,8 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         c->tune_probes = (uint32_t)value & 0xFu;
     } else if (!strcmp(name, "stream_probes")) {
         c->tune_stream_probes = (uint32_t)value & 0xFu;
+    } else if (!strcmp(name, "stream_rotate")) {
+        c->tune_stream_rotate = (uint32_t)value;
     } else if (!strcmp(name, "diag_buffer")) {
         c->diag = (uint64_t*)(uintptr_t)value;        /* device pointer, 4 x u64 per wave of the grid; 0 = off */
     } else {
@@ -498,6 +501,10 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         }
     }
     const bool staged = nstage > 1;
+    /* survivor-stream writers move to the next region after every block: the 8 regions come out equally
+     * long with the same mix of blocks, so the reading pass is balanced with little stealing (measured,
+     * profiles/r01_region_rotation.txt: C2 0.883 -> 0.831 ms, C3 0.598 -> 0.539 ms; regions by XCD = 1) */
+    const uint32_t rotate_regions = c->tune_stream_rotate == 1u ? 0u : 1u;
     const bool pool_stream = staged && (c->tune_staging ? c->tune_staging : 3u) == 3u;
 
     /* ---- geometry of the tile pass -------------------------------------------------------------- */
@@ -596,6 +603,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.out.base = (uint8_t*)c->stream_buf[0];
         a.out.n_blocks = stage_counter(c, 0);
         a.out.region_blocks = region_blocks;
+        a.out.rotate = rotate_regions;
     }
     a.diag = c->diag;
     hipError_t e;
@@ -630,6 +638,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.out.base = (uint8_t*)c->stream_buf[k & 1];
         a.out.n_blocks = stage_counter(c, k);
         a.out.region_blocks = region_blocks;
+        a.out.rotate = rotate_regions;
         memset(&a.q, 0, sizeof(a.q));
         a.q.heads = stage_heads(c, k);
         /* a block of 64 records costs at most (i1 - i0) iterations: uniform, claim a few at a time */
@@ -638,7 +647,11 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 16u;
         a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 2u;
         if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
-        a.q.flags = (tq.flags & kQueuePrefetch) | (c->tune_stream_probes << kQueueProbeShift);
+        {
+            uint32_t probes = c->tune_stream_probes ? c->tune_stream_probes : (rotate_regions ? 4u : 0u);
+            if (sgrid < 64u) probes = 0;
+            a.q.flags = (tq.flags & kQueuePrefetch) | (probes << kQueueProbeShift);
+        }
         a.diag = c->diag ? c->diag + (size_t)k * c->diag_stride : nullptr;
         if (pool_stream) {
             a.i0 = bounds[0];

@@ -63,7 +63,8 @@ struct StreamRef {
     uint8_t* base;               /* kShards regions of region_blocks blocks each */
     uint32_t* n_blocks;          /* kShards device counters, kShardStrideWords apart: blocks appended per region */
     uint32_t region_blocks;      /* capacity of one region; 8 regions hold 1.5x the worst-case total */
-    uint32_t pad_;
+    uint32_t rotate;             /* writers move to the next region after every block: equal-length regions
+                                  * with the same mix of light and heavy blocks (the reader then needs no stealing) */
 };
 
 /* Queue geometry of one launch. */
@@ -511,7 +512,10 @@ struct RingWriter {
             uint32_t v = 0;
             if (lane == 0) v = atomicAdd(&out.n_blocks[region * kShardStrideWords], 1u);
             blk = __builtin_amdgcn_readfirstlane(v);
-            if (blk < out.region_blocks) return true;
+            if (blk < out.region_blocks) {
+                if (out.rotate) home = (region + 1u) & (uint32_t)(kShards - 1);
+                return true;
+            }
         }
         return false;                                      /* cannot happen: capacity is worst-case x 1.5 */
     }
