@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfractalrenderer_amd.so")
+# FR_LIB_PATH: load another build of the same library (A/B runs of two kernel versions in one GPU session)
+LIB_PATH = os.environ.get("FR_LIB_PATH") or os.path.join(_HERE, "libfractalrenderer_amd.so")
 
 FR_OK = 0
 FR_ERR_INVALID_ARG = -1

@@ -250,15 +250,22 @@ static bool exact_division_ok(fr_ctx* c, uint32_t W, uint32_t H, bool julia, boo
     return ok;
 }
 
+template <typename T, int FRACTAL, bool EFFECTS, bool SSAA>
+static hipError_t launch_tile_aa(int shape, dim3 grid, hipStream_t s, const LaunchArgs& a)
+{
+    switch (shape) {
+    case 6: hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 6, EFFECTS, SSAA>), grid, dim3(kBlockThreads), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 4, EFFECTS, SSAA>), grid, dim3(kBlockThreads), 0, s, a); break;
+    default: hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 3, EFFECTS, SSAA>), grid, dim3(kBlockThreads), 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
 template <typename T, int FRACTAL, bool EFFECTS>
 static hipError_t launch_tile(int shape, dim3 grid, hipStream_t s, const LaunchArgs& a)
 {
-    switch (shape) {
-    case 6: hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 6, EFFECTS>), grid, dim3(kBlockThreads), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 4, EFFECTS>), grid, dim3(kBlockThreads), 0, s, a); break;
-    default: hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 3, EFFECTS>), grid, dim3(kBlockThreads), 0, s, a); break;
-    }
-    return hipGetLastError();
+    return a.aa > 1 ? launch_tile_aa<T, FRACTAL, EFFECTS, true>(shape, grid, s, a)
+                    : launch_tile_aa<T, FRACTAL, EFFECTS, false>(shape, grid, s, a);
 }
 
 template <typename T, int FRACTAL>

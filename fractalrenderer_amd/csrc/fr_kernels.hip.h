@@ -742,7 +742,7 @@ __device__ __forceinline__ void diag_write(const LaunchArgs& A, uint32_t lane, u
  * FRACTAL: 0 Mandelbrot, 1 Julia, 2 Burning Ship.  FPW_LOG2: log2 of the sub-tile width (3: 8x8, 4: 16x4, 6: 64x1).
  * EFFECTS: trap / stripe / interior-style variant (Mandelbrot and Burning Ship, never staged).
  * Runs iterations [0, A.i1); when A.i1 < max_iter the samples still alive go to A.out. */
-template <typename T, int FRACTAL, int FPW_LOG2, bool EFFECTS>
+template <typename T, int FRACTAL, int FPW_LOG2, bool EFFECTS, bool SSAA>
 __global__ void __launch_bounds__(kBlockThreads)
 tile_kernel(const LaunchArgs A)
 {
@@ -761,7 +761,8 @@ tile_kernel(const LaunchArgs A)
     /* viewport constants out of LDS (broadcast reads), narrowed as the reference narrows
      * them for its fp32 shaders (src/compute_effect_manager.h:85-90) */
     const int W = S.W, H = S.H, max_iter = S.max_iter;
-    const int aa = S.aa > 1 ? S.aa : 1;
+    /* SSAA = false: the one-sample variant (the sample loop and its state fold away: fewer live SGPRs) */
+    const int aa = SSAA ? (S.aa > 1 ? S.aa : 1) : 1;
     const T center_x = (T)S.center_x, center_y = (T)S.center_y, zoom = (T)S.zoom;
     const T bailout = (T)S.bailout;
     const T B2 = bailout * bailout;
@@ -772,7 +773,7 @@ tile_kernel(const LaunchArgs A)
     /* planes nobody asked for are not computed (wave-uniform branches) */
     const bool want_rgb = A.rgba != nullptr;
     const bool want_nu = want_rgb || A.nu != nullptr;
-    const bool staged = !EFFECTS && A.i1 < max_iter;        /* survivors continue in the stream pass */
+    const bool staged = !EFFECTS && !SSAA && A.i1 < max_iter;        /* survivors continue in the stream pass */
     const int i1 = EFFECTS ? max_iter : A.i1;
     (void)inv_w; (void)aspect; (void)H;
 
