@@ -488,7 +488,9 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         auto_first = auto_first < 32 ? 32 : (auto_first > 128 ? 128 : auto_first);
         const int first = c->tune_stage_first ? (int)c->tune_stage_first : auto_first;
         const int ratio = c->tune_stage_ratio >= 2 ? (int)c->tune_stage_ratio : 4;
-        if (allow && max_iter >= 2 * first) {
+        /* below ~4 budgets the second launch costs more than it balances (measured at max_iter 64: 0.32 ms
+         * staged, 0.25 ms as one bounded pass) */
+        if (allow && max_iter >= (c->tune_stage_first ? 2 : 4) * first) {
             long long b = first - first % kFastBlock;            /* budgets are multiples of the unchecked block */
             if (b < kFastBlock) b = kFastBlock;
             while (b < max_iter && nstage < kMaxStages - 1) {
@@ -549,7 +551,11 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      *    saturate the queue words (~88 dequeues/us each: a 0.44 ms floor): short runs of 2..8;
      *  - staged tile pass: every sub-tile costs at most b0 iterations, so long runs are safe and
      *    hide the dequeue latency that dominates cheap sub-tiles. */
-    if (staged) {
+    /* bounded, cheap items: the staged tile pass, and an unstaged pass whose samples run at most 128 updates
+     * (measured at max_iter <= 32: 0.31 ms with short runs -- the queue words saturate -- 0.17 ms with long) */
+    const int aa1 = p->antialiasing_samples > 1 ? p->antialiasing_samples : 1;
+    const bool bounded = staged || (!effects && (long long)max_iter * aa1 * aa1 <= 128);
+    if (bounded) {
         tq.run_shift = clamp_shift((int)ceil_log2(2u * waves_per_shard));
         tq.run_max = c->tune_run_max ? c->tune_run_max : 32u;
         tq.run_min = c->tune_run_min ? c->tune_run_min : 4u;
@@ -567,7 +573,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      * a 1/8 shard, profiles/r01_probe_limit.txt).  Unstaged passes keep full stealing: their items cost
      * anything between 1 and max_iter iterations. */
     {
-        uint32_t probes = c->tune_probes ? c->tune_probes : ((staged && grid >= 64u) ? 1u : 0u);
+        uint32_t probes = c->tune_probes ? c->tune_probes : ((bounded && grid >= 64u) ? 1u : 0u);
         if (grid < (uint32_t)kShards) probes = 0;          /* fewer workgroups than shards: everybody probes everything */
         tq.flags |= probes << kQueueProbeShift;
     }

@@ -274,7 +274,7 @@ def test_staged_equals_single_pass(fr, renderer, oracle, name):
             n = renderer.last_stages()
         finally:
             renderer.set_option("staging", 0)
-        assert n > 1 or p.max_iterations < 64
+        assert n > 1 or p.max_iterations < 128
         for a, b in zip(staged, single):
             assert np.array_equal(a, b), mode
 
