@@ -215,7 +215,12 @@ class FrameExchange:
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.device)  # noqa: E731
         N = self.world
         self.send = [mk((N, self.rows_local, width) + tail, pdt) for _ in range(slots)]
-        self.recv = [[mk((self.rows_of[r], width) + tail, pdt) for r in range(N)] for _ in range(slots)]
+        if self.even:
+            # equal shares: one receive tensor per slot, so that the de-interleave is ONE strided copy
+            self.recv_all = [mk((N, self.rows_local, width) + tail, pdt) for _ in range(slots)]
+            self.recv = [[ra[r] for r in range(N)] for ra in self.recv_all]
+        else:
+            self.recv = [[mk((self.rows_of[r], width) + tail, pdt) for r in range(N)] for _ in range(slots)]
         self.frame_nu = [mk((height, width), nu_dtype) for _ in range(slots)] if payload == "nu" else [None] * slots
         self.frame_rgba = [mk((height, width, 4), torch.float32) for _ in range(slots)]
         self.frame_index = [-1] * slots          # which frame this rank's slot holds (-1: none)
@@ -269,10 +274,11 @@ class FrameExchange:
         N = self.world
         frame = self.frame_nu[b] if self.payload == "nu" else self.frame_rgba[b]
         if self.even:
+            # frame rows = [strip s of rank 0, strip s of rank 1, ...]: (S, N, R, W) <- (N, S, R, W) transposed
             S = self.H // (N * self.R)
-            fv = frame.view((S, N, self.R, self.W) + tuple(frame.shape[2:]))
-            for p, part in enumerate(self.recv[b]):
-                fv[:, p].copy_(part.view((S, self.R, self.W) + tuple(frame.shape[2:])))
+            tail = tuple(frame.shape[2:])
+            frame.view((S, N, self.R, self.W) + tail).copy_(
+                self.recv_all[b].view((N, S, self.R, self.W) + tail).transpose(0, 1))
         else:
             for p, part in enumerate(self.recv[b]):
                 if part.shape[0]:

@@ -23,7 +23,7 @@ def main():
     dev = torch.device("cuda:0")
     W = H = args.size
     st = fr.FractalState(max_iterations=args.max_iter)
-    nctx = 4
+    nctx = 8
     rs = [fr.Renderer(0) for _ in range(nctx)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nctx)]
     for o in args.opt:
@@ -74,7 +74,7 @@ def main():
 
             t1 = timed(seq)
             line = "N=%d plane=%-4s  seq %.3f ms/group (%.2fx)" % (N, plane, t1, N * base / t1)
-            for k in (2, 4):
+            for k in (2, 4, 8):
                 if N >= k:
                     tk = timed(multi(k))
                     line += "   %d streams %.3f ms (%.2fx)" % (k, tk, N * base / tk)
