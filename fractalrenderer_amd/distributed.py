@@ -354,3 +354,74 @@ class FrameExchange:
             for lane in getattr(self, "lanes", [self.compute]):
                 lane.synchronize()
             self.comm.synchronize()
+
+
+def export_animation(anim, renderers, output_folder: str, *, fractal_type=None, precision=None,
+                     width: Optional[int] = None, height: Optional[int] = None, frames=None,
+                     device: Optional[torch.device] = None, rows_per_strip: int = 0, group=None) -> List[str]:
+    """AnimationRenderer::start_render (src/animation_renderer.cpp:26-152) over the GPUs of a node: the
+    BASELINE.json C5 pipeline (.franim sweep, row-band sharded frames, RCCL exchange).
+
+    Every frame is cut into row strips over all ranks; frames are processed in groups of `world`, frame
+    j of a group is gathered to rank j (FrameExchange), which then runs what the reference's
+    RenderFrameCallback does after its dispatch (src/vk_engine.cpp:1266-1381): the 8-bit export (second
+    tonemap, u8, flip -- fr_export_rgb8 on the GPU) and the PNG (`frame_%06d.png`), so the readback and
+    the deflate are spread over the ranks too.  The files are byte-identical to the ones
+    Renderer.render_frame writes on one GPU.  `renderers`: this rank's render contexts, one per render
+    lane.  Returns the paths THIS rank wrote.  Call on every rank with the same arguments."""
+    import numpy as np  # noqa: F401  (torch -> numpy for the PNG writer)
+    from .renderer import write_png, frame_path, Renderer
+    from .state import FractalType, Precision
+
+    fractal_type = FractalType.Mandelbrot if fractal_type is None else fractal_type
+    precision = Precision.F32 if precision is None else precision       # what the reference's shaders compute in
+    info = anim.info
+    if info.keyframe_count < 2:
+        raise ValueError("need at least 2 keyframes")                    # src/animation_renderer.cpp:35-42
+    W, H = width or info.export_width, height or info.export_height
+    total = anim.frame_count()                                           # :48
+    todo = [f for f in (frames if frames is not None else range(total)) if 0 <= f < total]
+    states = {f: anim.interpolate(anim.frame_time(f)) for f in todo}     # :80-83
+    r0 = renderers[0]
+    deep = fractal_type == FractalType.Deep_Zoom
+    payload = "nu" if all(Renderer.colorize_supported(s, fractal_type, precision) for s in states.values()) else "rgba"
+    nu_dtype = torch.float64 if precision == Precision.F64 else torch.float32
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    fx = FrameExchange(W, H, payload=payload, nu_dtype=nu_dtype, device=dev, rows_per_strip=rows_per_strip,
+                       group=group, render_lanes=len(renderers))
+
+    def render_fn(shard, out, idx, plane, lane=0):
+        # the storage image of the reference holds the post-chained colour (shaders/mandelbrot.comp:233-237)
+        renderers[lane].render(states[todo[idx]], W, H, fractal_type=fractal_type, precision=precision,
+                               post_chain=(plane == "rgba" and not deep), shard=shard, sync=False,
+                               stream=torch.cuda.current_stream().cuda_stream, **{plane: out})
+
+    def colorize_fn(nu_frame, rgba_frame, idx):
+        r0.colorize(states[todo[idx]], nu_frame, rgba_frame, fractal_type=fractal_type, precision=precision,
+                    post_chain=True, stream=torch.cuda.current_stream().cuda_stream)
+
+    written: List[str] = []
+
+    def finish(slot):
+        fx.wait(slot)
+        idx = fx.frame_index[slot]
+        if idx < 0:
+            return
+        rgb8 = r0.export_rgb8(fx.frame_rgba[slot], W, H, through_half=True)      # src/vk_engine.cpp:1313-1371
+        path = frame_path(output_folder, todo[idx])                              # src/animation_renderer.cpp:86-88
+        write_png(path, rgb8.cpu().numpy())                                      # src/vk_engine.cpp:1374-1381
+        written.append(path)
+
+    fx.prime()
+    pending = []
+    i = 0
+    while i < len(todo):
+        count = min(fx.world, len(todo) - i)
+        pending.append(fx.submit_group(render_fn, i, count, colorize_fn if payload == "nu" else None))
+        if len(pending) == fx.nslots:            # group g's export + PNG overlap the rendering of group g+1
+            finish(pending.pop(0))
+        i += count
+    for slot in pending:
+        finish(slot)
+    fx.drain()
+    return written
