@@ -11,9 +11,12 @@ final gather of disjoint byte ranges:
     dist.gather(shard_buf -> root)                             (RCCL send/recv, comm stream)
     root: de-interleave the gathered strips into the frame     (one strided copy, comm stream)
 
-For a frame sequence (.franim sweep) the buffers are double-buffered so that gather(frame n)
-overlaps render(frame n+1).  The reference has no multi-GPU path; this is new design
-(BASELINE.json north_star: "disjoint row bands with a final RCCL gather over xGMI").
+StripGather (above) brings ONE frame to one root.  For a frame sequence (.franim sweep, bench.py)
+FrameExchange rotates the root from frame to frame and ships the smooth-count plane instead of the
+colour, which takes the exchange off the critical path (see its docstring for the link budget), and
+export_animation builds the reference's offline animation render on top of it.  The reference has no
+multi-GPU path; this is new design (BASELINE.json north_star: "disjoint row bands with a final RCCL
+gather over xGMI").
 """
 from __future__ import annotations
 
