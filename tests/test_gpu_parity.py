@@ -729,3 +729,41 @@ def test_distributed_animation_export_matches_single_gpu_pngs(fr, renderer, tmp_
         ref_path = str(tmp_path / ("ref_%06d.png" % f))
         assert renderer.render_frame(anim.interpolate(anim.frame_time(f)), 192, 128, ref_path)
         assert open(ref_path, "rb").read() == open(os.path.join(out_dir, "frame_%06d.png" % f), "rb").read(), f
+
+
+def test_randomised_views_match_the_oracle(fr, renderer, oracle):
+    """Seeded sweep over the parameter space (fractal, precision, view, iteration budget, bailout, palette,
+    frame shape, row-strip shard): escape indices bit-exact, nu and colour within the stated bars.  Views are
+    drawn around points of the sets' boundaries so that frames mix interior, slow and fast escapes."""
+    rng = np.random.default_rng(20261004)
+    anchors = {0: [(-0.743643887037151, 0.13182590420533), (-0.1011, 0.9563), (-1.25066, 0.02012), (0.275, 0.0),
+                   (-0.5, 0.0), (-1.7497, 0.00001)],
+               1: [(0.0, 0.0), (0.3, 0.2), (-0.6, 0.1)],
+               2: [(-1.755, -0.03), (-0.5, -0.5), (-1.62, -0.002)]}
+    for trial in range(48):
+        fractal = int(rng.integers(0, 3))
+        prec = int(rng.integers(0, 2))
+        ax, ay = anchors[fractal][int(rng.integers(0, len(anchors[fractal])))]
+        zoom = float(10.0 ** rng.uniform(-4.0 if prec == 1 else -2.0, 0.6))
+        W, H = int(rng.integers(9, 180)), int(rng.integers(5, 120))
+        kw = dict(fractal=fractal, precision=prec, center_x=ax + zoom * float(rng.uniform(-0.2, 0.2)),
+                  center_y=ay + zoom * float(rng.uniform(-0.2, 0.2)), zoom=zoom,
+                  max_iterations=int(rng.choice([1, 7, 33, 64, 127, 128, 129, 300, 777, 1500, 3000])),
+                  bailout=float(rng.choice([1.5, 2.0, 2.5, 4.0, 4.0, 4.0, 16.0, 1000.0])),
+                  palette_mode=int(rng.integers(0, 6 if fractal == 0 else 10)),
+                  color_offset=float(np.float32(rng.uniform(0, 1))), color_scale=float(np.float32(rng.uniform(0.5, 6))),
+                  interior_style=int(rng.choice([0, 0, 1])), post_chain=int(rng.integers(0, 2)))
+        if fractal == 1:
+            kw.update(julia_c_real=float(rng.uniform(-0.9, 0.4)), julia_c_imag=float(rng.uniform(-0.7, 0.7)))
+        p = oracle.OracleParams(**kw)
+        ref = oracle.render(p, W, H)
+        shard = None
+        if trial % 3 == 1:
+            nparts = int(rng.integers(2, 6))
+            shard = fr.Shard(int(rng.integers(0, nparts)), nparts, int(rng.integers(1, 9)))
+        rgba, nu, it = gpu_render(fr, renderer, p, W, H, shard=shard)
+        rows = shard.global_rows(H) if shard else slice(None)
+        try:
+            check_against(p, ref.iter[rows], ref.nu[rows], ref.rgba[rows], rgba, nu, it)
+        except AssertionError as e:
+            raise AssertionError("trial %d %r %dx%d shard %r: %s" % (trial, kw, W, H, shard, e))
