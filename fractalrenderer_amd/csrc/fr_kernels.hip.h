@@ -1180,7 +1180,9 @@ pool_kernel(const LaunchArgs A)
 
     /* per-lane state */
     uint32_t pixel = kInvalidPixel;      /* kInvalidPixel: lane is free */
-    bool fin = false;                    /* finished, waiting to be shaded and stored */
+    uint32_t fin = 0;                    /* 1: finished, waiting to be shaded and stored (a VGPR flag, not a
+                                          * lane mask: a divergent bool carried through the iteration loops costs
+                                          * mask-merging scalar instructions in every iteration) */
     Orbit<T> o;
     o.X = o.Yd = o.cx = o.cyd = o.x2 = o.y2d = T(0);
     uint32_t deadline = 0;
@@ -1195,8 +1197,8 @@ pool_kernel(const LaunchArgs A)
 
     for (;;) {
         /* ---- retire: shade and store the finished lanes ---- */
-        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
-            if (fin) {
+        if (__builtin_amdgcn_ballot_w64(fin != 0u) != 0ull) {
+            if (fin != 0u) {
                 T nu;
                 float rgb[3];
                 shade<T, FRACTAL>(A, S, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
@@ -1206,7 +1208,7 @@ pool_kernel(const LaunchArgs A)
                 if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = nu;
                 if (A.iter) A.iter[pixel] = esc_i;
                 pixel = kInvalidPixel;
-                fin = false;
+                fin = 0u;
             }
         }
         /* ---- refill the free lanes from the reserve ---- */
@@ -1329,10 +1331,10 @@ pool_kernel(const LaunchArgs A)
         uint32_t newly = 0;
         /* lanes whose deadline is reached are interior; then find the next earliest deadline */
         auto reach_deadline = [&](bool at_or_past) {
-            const bool running = pixel != kInvalidPixel && !fin;
+            const bool running = pixel != kInvalidPixel && fin == 0u;
             const bool hit = running && (at_or_past ? (int32_t)(wclock - deadline) >= 0 : deadline == wclock);
             if (hit) {
-                esc_i = max_iter; esc_r2 = T(0); fin = true;
+                esc_i = max_iter; esc_r2 = T(0); fin = 1u;
                 o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
             }
             newly += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
@@ -1340,6 +1342,7 @@ pool_kernel(const LaunchArgs A)
             have_running = rel != 0xFFFFFFFFu;
             next_deadline = wclock + (have_running ? rel : (uint32_t)max_iter);
         };
+        uint32_t clean = 0;            /* tested updates since the last escape */
         while (newly < goal) {
             if (fast) {
                 const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
@@ -1355,26 +1358,38 @@ pool_kernel(const LaunchArgs A)
                 o.X = sX; o.Yd = sYd; o.x2 = sx2; o.y2d = sy2d;      /* roll back, replay tested */
                 fast = false;
             }
-            bool any_escape = false;
-            for (int k = 0; k < kFastBlock && newly < goal; ++k) {
+            /* tested stretch: up to the next deadline, at most one block.  The loop carries a countdown and
+             * one vector-compare branch; goal and deadline are only looked at where they can change (on an
+             * escape event / after the stretch).  On escape-dense views such as the C3 Julia dust the scalar
+             * bookkeeping of per-iteration tests made the pass SALU-bound (147 M scalar against 98 M vector
+             * instructions per frame, one scalar issue port per CU). */
+            uint32_t n = next_deadline - wclock;                 /* >= 1: deadlines lie ahead of the clock */
+            if (n > (uint32_t)kFastBlock) n = (uint32_t)kFastBlock;
+            uint32_t k = 0;
+            bool escaped = false;
+            do {
                 orbit_step<T, Form<FRACTAL>::abs_step>(o);
                 const T r2 = orbit_r2(o);
                 const bool e = r2 > B2;
                 const uint64_t em = __builtin_amdgcn_ballot_w64(e);
+                ++k;
                 if (em != 0ull) {
                     if (e) {
-                        esc_i = (int)(wclock - (deadline - (uint32_t)max_iter));
+                        esc_i = (int)(wclock + k - 1u - (deadline - (uint32_t)max_iter));
                         esc_r2 = r2;
-                        fin = true;
+                        fin = 1u;
                         o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
                     }
                     newly += (uint32_t)__builtin_popcountll(em);
-                    any_escape = true;
+                    escaped = true;
+                    if (newly >= goal) break;
                 }
-                ++wclock;
-                if (wclock == next_deadline) reach_deadline(false);
-            }
-            fast = fast_ok && !any_escape;
+            } while (k < n);
+            wclock += k;
+            clean = escaped ? 0u : clean + k;
+            if (wclock == next_deadline) reach_deadline(false);
+            /* back to unchecked blocks after a block's worth of updates without an escape */
+            if (clean >= (uint32_t)kFastBlock) { fast = fast_ok; clean = 0; }
         }
     }
     diag_write(A, lane, diag_t0, diag_items, diag_claims);
