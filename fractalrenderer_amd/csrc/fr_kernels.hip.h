@@ -633,28 +633,29 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
             o = snap;                /* roll back, replay tested */
             fast = false;
         }
-        /* tested block */
-        const int n = left < kFastBlock ? left : kFastBlock;
-        bool any_escape = false;
-        for (int k = 0; k < n; ++k) {
+        /* tested block: the loop carries one counter and one vector-compare branch (scalar instructions
+         * share ONE issue port per CU: per-iteration scalar bookkeeping is what bounds escape-dense views) */
+        int end = i + (left < kFastBlock ? left : kFastBlock);
+        const uint64_t before = done;
+        do {
             orbit_step<T, ABS>(o);
             const T r2 = orbit_r2(o);
             const bool e = r2 > B2;
             const uint64_t em = __builtin_amdgcn_ballot_w64(e);
             if (em != 0ull) {
                 if (e) {
-                    esc_i = i + k;
+                    esc_i = i;
                     esc_r2 = r2;
                     /* park at the fixed point z = 0 of c = 0: never "escapes" again */
                     o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
                 }
                 done |= em;
-                any_escape = true;
-                if (done == ~0ull) return;
+                if (done == ~0ull) end = i;      /* single-exit loop: everybody finished -> this was the last update */
             }
-        }
-        i += n;
-        fast = fast_ok && !any_escape;
+            ++i;
+        } while (i < end);
+        if (done == ~0ull) return;
+        fast = fast_ok && done == before;
     }
 }
 
@@ -1382,7 +1383,7 @@ pool_kernel(const LaunchArgs A)
                     }
                     newly += (uint32_t)__builtin_popcountll(em);
                     escaped = true;
-                    if (newly >= goal) break;
+                    if (newly >= goal) n = k;        /* single-exit loop: goal reached -> this was the last update */
                 }
             } while (k < n);
             wclock += k;
