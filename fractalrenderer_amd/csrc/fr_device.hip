@@ -482,10 +482,10 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
          * C2 (+5 %), C3 (+30 %), C5 (+40 %), 1 % slower on C4 (profiles/r01_staging_sweeps.txt) */
         const uint32_t mode = c->tune_staging ? c->tune_staging : 3u;
         const bool allow = !effects && p->antialiasing_samples <= 1 && (mode == 2 || mode == 3);
-        /* tile-pass budget: ~max_iter/48 rounded to the unchecked block, within [32, 128] (measured best:
-         * 32 at max_iter 1024, 48 at 2048, 96-128 at 4096) */
-        int auto_first = ((max_iter / 48 + kFastBlock / 2) / kFastBlock) * kFastBlock;
-        auto_first = auto_first < 32 ? 32 : (auto_first > 128 ? 128 : auto_first);
+        /* tile-pass budget: ~max_iter/28 rounded to the unchecked block, within [32, 192] (measured best:
+         * 32 at max_iter 1024, 64 at 2048, 128-192 at 4096, flat at 16384) */
+        int auto_first = ((max_iter / 28 + kFastBlock / 2) / kFastBlock) * kFastBlock;
+        auto_first = auto_first < 32 ? 32 : (auto_first > 192 ? 192 : auto_first);
         const int first = c->tune_stage_first ? (int)c->tune_stage_first : auto_first;
         const int ratio = c->tune_stage_ratio >= 2 ? (int)c->tune_stage_ratio : 4;
         /* below ~4 budgets the second launch costs more than it balances (measured at max_iter 64: 0.32 ms

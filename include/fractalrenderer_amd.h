@@ -209,7 +209,7 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "staging"            3 = tile pass for the first "stage_first" iterations + ONE lane-pool pass over the
  *                        compacted survivors to max_iter, 2 = tile pass + block stream passes, 1 = single pass,
  *                        0 = automatic (= 3 wherever it applies: no SSAA, no trap/stripe effects)
- *   "stage_first"        iteration budget of the tile pass (default ~max_iter/48 within [32, 128])
+ *   "stage_first"        iteration budget of the tile pass (default ~max_iter/28 within [32, 192])
  *   "stage_ratio"        budget growth per stream pass (default 4)
  *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue may claim in a stream pass
  *   "stream_workgroups_per_cu"          workgroups per compute unit of the stream pass
