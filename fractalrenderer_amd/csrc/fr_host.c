@@ -228,7 +228,16 @@ static void ramp_fifths(fr_palette_table* t)
     for (int i = 0; i < 5; ++i) { t->seg_lo[i] = lo[i]; t->seg_k[i] = 5.0f; t->seg_div[i] = 0; }
 }
 
+static void palette_table_fill(int shader, int mode, fr_palette_table* t);
+
 void fr_palette_table_build(int shader, int mode, fr_palette_table* t)
+{
+    palette_table_fill(shader, mode, t);
+    t->any_div = 0;
+    for (int i = 0; i < t->nseg && i < 5; ++i) t->any_div |= t->seg_div[i] != 0;
+}
+
+static void palette_table_fill(int shader, int mode, fr_palette_table* t)
 {
     /* knots: shaders/mandelbrot.comp:60-131 and shaders/julia.comp:20-163 */
     static const float fire[5][3]       = {{0.0f,0.0f,0.1f},{0.8f,0.0f,0.0f},{1.0f,0.3f,0.0f},{1.0f,0.9f,0.0f},{1.0f,1.0f,0.95f}};

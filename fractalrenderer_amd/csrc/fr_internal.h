@@ -41,6 +41,7 @@ typedef struct fr_palette_table {
     float   seg_lo[5];       /* segment k covers w in [seg_lo[k], seg_lo[k+1])      */
     float   seg_k[5];        /* mix factor = (w - seg_lo[k]) * seg_k[k]  or / seg_k[k] */
     int32_t seg_div[5];      /* 1: divide by seg_k, 0: multiply                      */
+    int32_t any_div;         /* some segment divides (lets the kernels skip the divide otherwise) */
     float   knot[6][4];      /* RGB knots (4th lane padding); knot[k], knot[k+1] bound segment k */
 } fr_palette_table;
 

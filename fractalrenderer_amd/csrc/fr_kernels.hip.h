@@ -203,6 +203,11 @@ __device__ __forceinline__ double log2_pos(double x)
 /* fp32: the hardware log2 (v_log_f32, ~1 ulp), which is also what a GLSL log() lowers to */
 __device__ __forceinline__ float log2_pos(float x) { return __builtin_amdgcn_logf(x); }
 
+/* Marks a rarely taken branch: the optimiser otherwise evaluates BOTH sides of a cheap-looking if/else and
+ * selects (found in the ISA: the 12-instruction IEEE fp64 divide ran next to its 3-op replacement for every
+ * pixel).  An empty volatile asm cannot be speculated, so the branch stays a branch. */
+__device__ __forceinline__ void cold_path() { asm volatile("" ::: "memory"); }
+
 /* Correctly rounded a/b from y = RN(1/b) without a divide (Markstein): q = RN(a*y),
  * r = a - b*q exactly (fma), q' = RN(q + r*y).  The host enables this only after checking, for
  * every column and row coordinate of the frame, that q' equals the IEEE quotient. */
@@ -248,7 +253,11 @@ __device__ __forceinline__ void palette_eval(const fr_palette_table& pal, float 
         return;
     }
     const float d = w - pal.seg_lo[seg];
-    const float k = pal.seg_div[seg] ? d / pal.seg_k[seg] : d * pal.seg_k[seg];
+    float k = d * pal.seg_k[seg];
+    if (pal.any_div) {                      /* only julia.comp's cosmic and lava ramps divide (:87-101, :149-163) */
+        cold_path();
+        if (pal.seg_div[seg]) k = d / pal.seg_k[seg];
+    }
     const float* a = pal.knot[seg];
     const float* b = pal.knot[seg + 1];
     for (int c = 0; c < 3; ++c) rgb[c] = a[c] * (1.0f - k) + b[c] * k;   /* GLSL mix */
@@ -834,6 +843,7 @@ tile_kernel(const LaunchArgs A)
                         uvx = div_by<T>((T)px - T(0.5) * resx, resy, inv_h);
                         uvy = div_by<T>((T)py - T(0.5) * resy, resy, inv_h);
                     } else {
+                        cold_path();
                         const int sy = s / aa, sx = s - sy * aa;
                         const T pxs = (T)px + (T)sx / (T)aa;
                         const T pys = (T)py + (T)sy / (T)aa;
@@ -904,6 +914,7 @@ tile_kernel(const LaunchArgs A)
                         uvx = div_by<T>((T)px, resx, inv_w);
                         uvy = div_by<T>((T)py, resy, inv_h);
                     } else {
+                        cold_path();
                         uvx = (T)px / resx; uvy = (T)py / resy;
                         if (aa > 1) {
                             const int sx = s / aa, sy = s - sx * aa;
@@ -1270,6 +1281,7 @@ pool_kernel(const LaunchArgs A)
                                     uvx = div_by<T>((T)px - T(0.5) * resx, resy, inv_h);
                                     uvy = div_by<T>((T)py - T(0.5) * resy, resy, inv_h);
                                 } else {
+                                    cold_path();
                                     uvx = ((T)px - T(0.5) * resx) / resy;
                                     uvy = ((T)py - T(0.5) * resy) / resy;
                                 }
@@ -1282,6 +1294,7 @@ pool_kernel(const LaunchArgs A)
                                     uvx = div_by<T>((T)px, resx, inv_w);
                                     uvy = div_by<T>((T)py, resy, inv_h);
                                 } else {
+                                    cold_path();
                                     uvx = (T)px / resx; uvy = (T)py / resy;
                                 }
                                 const T mx = center_x + (uvx - T(0.5)) * zoom * aspect;
