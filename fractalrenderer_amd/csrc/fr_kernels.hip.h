@@ -1357,20 +1357,30 @@ pool_kernel(const LaunchArgs A)
             next_deadline = wclock + (have_running ? rel : (uint32_t)max_iter);
         };
         uint32_t clean = 0;            /* tested updates since the last escape */
+        uint32_t streak = 0;           /* clean unchecked blocks in a row */
         while (newly < goal) {
             if (fast) {
                 const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
+                /* after two clean blocks in a row the wave doubles the unchecked stretch (half the snapshot /
+                 * test overhead on the long interior runs that dominate deep views); one dirty block resets it */
+                const bool twice = streak >= 2u;
 #pragma unroll
                 for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
+                if (twice) {
+#pragma unroll
+                    for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
+                }
                 const T r2 = orbit_r2(o);
                 if (__builtin_amdgcn_ballot_w64(!(r2 <= B2)) == 0ull) {
-                    wclock += (uint32_t)kFastBlock;
+                    wclock += twice ? 2u * (uint32_t)kFastBlock : (uint32_t)kFastBlock;
+                    ++streak;
                     /* clean block: lanes at or past their deadline never escaped -> interior */
                     if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
                     continue;
                 }
                 o.X = sX; o.Yd = sYd; o.x2 = sx2; o.y2d = sy2d;      /* roll back, replay tested */
                 fast = false;
+                streak = 0;
             }
             /* tested stretch: up to the next deadline, at most one block.  The loop carries a countdown and
              * one vector-compare branch; goal and deadline are only looked at where they can change (on an
