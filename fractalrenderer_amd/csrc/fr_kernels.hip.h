@@ -1361,18 +1361,16 @@ pool_kernel(const LaunchArgs A)
         while (newly < goal) {
             if (fast) {
                 const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
-                /* after two clean blocks in a row the wave doubles the unchecked stretch (half the snapshot /
-                 * test overhead on the long interior runs that dominate deep views); one dirty block resets it */
-                const bool twice = streak >= 2u;
-#pragma unroll
-                for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
-                if (twice) {
+                /* after 2 (6) clean stretches in a row the wave runs 2 (4) blocks per snapshot / test (a half, a
+                 * quarter of that overhead on the long interior runs that dominate deep views); a dirty one resets it */
+                const uint32_t reps = streak >= 6u ? 4u : (streak >= 2u ? 2u : 1u);
+                for (uint32_t rep = 0; rep < reps; ++rep) {
 #pragma unroll
                     for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
                 }
                 const T r2 = orbit_r2(o);
                 if (__builtin_amdgcn_ballot_w64(!(r2 <= B2)) == 0ull) {
-                    wclock += twice ? 2u * (uint32_t)kFastBlock : (uint32_t)kFastBlock;
+                    wclock += reps * (uint32_t)kFastBlock;
                     ++streak;
                     /* clean block: lanes at or past their deadline never escaped -> interior */
                     if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
