@@ -1187,7 +1187,7 @@ pool_kernel(const LaunchArgs A)
     q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
-    uint32_t diag_items = 0, diag_claims = 0;
+    uint32_t diag_items = 0, diag_claims = 0, diag_dry = 0;
     if (A.diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
 
     /* per-lane state */
@@ -1228,7 +1228,12 @@ pool_kernel(const LaunchArgs A)
             const uint64_t freem = __builtin_amdgcn_ballot_w64(pixel == kInvalidPixel);
             if (freem == 0ull || dry) break;
             if (res_next == res_count * 64u) {
-                if (!q.next(res_begin, res_count, res_shard)) { dry = true; break; }
+                if (!q.next(res_begin, res_count, res_shard)) {
+                    dry = true;
+                    /* diagnostics: when this wave found the queue dry, in 100 MHz ticks since its start (bits 32..) */
+                    diag_dry = A.diag ? (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0) : 0u;
+                    break;
+                }
                 res_next = 0;
                 ++diag_claims;
                 diag_items += res_count;
@@ -1414,7 +1419,12 @@ pool_kernel(const LaunchArgs A)
             if (clean >= (uint32_t)kFastBlock) { fast = fast_ok; clean = 0; }
         }
     }
-    diag_write(A, lane, diag_t0, diag_items, diag_claims);
+    if (A.diag && lane == 0) {      /* as diag_write, with the dry time packed above the dequeue count */
+        const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+        uint64_t* d = A.diag + (size_t)wave_id * 4;
+        d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = diag_items;
+        d[3] = (uint64_t)diag_claims | ((uint64_t)diag_dry << 32);
+    }
 }
 
 /* ---- Deep_Zoom: the reference's perturbation shader ------------------------------------------------

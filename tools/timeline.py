@@ -48,7 +48,8 @@ for s in range(nst):
     if not ran.any():
         print(f"  stage {s}: no waves"); continue
     start = (ds[ran, 0] - t0) / 100.0; end = (ds[ran, 1] - t0) / 100.0
-    items, claims = ds[ran, 2], ds[ran, 3]
+    items, claims = ds[ran, 2], ds[ran, 3] & 0xFFFFFFFF
+    dry = (ds[ran, 3] >> 32) / 100.0 + start          # lane-pool passes: when the wave found the queue dry
     lo, hi = start.min(), end.max()
     edges = np.linspace(lo, hi, 11)
     live = [(np.minimum(end, b) - np.maximum(start, a)).clip(min=0).sum() / max(b - a, 1e-9) for a, b in zip(edges[:-1], edges[1:])]
@@ -58,5 +59,9 @@ for s in range(nst):
         A = np.vstack([np.ones(worked.sum()), items[worked], claims[worked]]).T
         coef = np.linalg.lstsq(A, dur, rcond=None)[0]
         print(f"           wave time ~ {coef[0]:.1f} us + {coef[1]:.2f} us/item + {coef[2]:.2f} us/dequeue  (start spread {np.percentile(start,99)-lo:.1f} us)")
+    if (ds[ran, 3] >> 32).any():
+        after = end - dry
+        print(f"           queue dry seen at p1 {np.percentile(dry,1)-lo:.1f} p50 {np.percentile(dry,50)-lo:.1f} p99 {np.percentile(dry,99)-lo:.1f} us; "
+              f"run-out after dry: p50 {np.percentile(after,50):.1f} p90 {np.percentile(after,90):.1f} p99 {np.percentile(after,99):.1f} max {after.max():.1f} us")
     print(f"  stage {s}: {lo:8.1f} -> {hi:8.1f} us ({hi-lo:7.1f}), waves {ran.sum()} ({worked.sum()} with work), items/wave mean {items[worked].mean() if worked.any() else 0:.1f} "
           f"max {items.max()}, dequeues {claims.sum()}, finish p50 {np.percentile(end,50)-lo:.1f} p99 {np.percentile(end,99)-lo:.1f}; live/10%: " + " ".join(f"{x:.0f}" for x in live))
