@@ -8,7 +8,7 @@ import fractalrenderer_amd as fr
 from bench import WORKLOADS
 ALL = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "subtile_shape", "staging", "stage_first", "stage_ratio",
        "stream_run_max", "stream_run_min", "stream_workgroups_per_cu", "queue_flags", "pool", "pool_refill_at", "pool_evict_at", "pool_passes",
-       "probes", "stream_probes", "stream_rotate")
+       "probes", "stream_probes", "stream_rotate", "stream_records")
 name, rounds = sys.argv[1], int(sys.argv[2])
 variants = sys.argv[3:] or [""]
 w = WORKLOADS[name]; W, H = w["W"], w["H"]
@@ -17,8 +17,12 @@ kw = dict(fractal_type=fr.FractalType[w["fractal"]], precision=fr.Precision[w["p
           rgba=torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0"))
 r = fr.Renderer(0)
 times = {v: [] for v in variants}
+import random
+random.seed(1)
 for rd in range(rounds + 1):
-    for v in variants:
+    order = list(variants)
+    random.shuffle(order)          # neighbours influence each other through clocks and power: shuffle per round
+    for v in order:
         for k in ALL: r.set_option(k, 0)
         for kv in filter(None, v.split(",")):
             k, val = kv.split("="); r.set_option(k, int(val, 0))
