@@ -1,29 +1,33 @@
 /*
  * fr_kernels.hip.h -- hand-written CDNA4 (gfx950) escape-time kernels.
  *
- * What is computed is the per-pixel loop of shaders/mandelbrot.comp:147-208 and
- * shaders/julia.comp:216-249 (z <- z^2 + c, update-then-test, smooth iteration count,
- * palette), in fp32 (what the reference does) or fp64.  How it is computed is
- * MI355X-first and shares nothing with the reference's 16x16-workgroup GLSL dispatch:
+ * What is computed is the per-pixel loop of shaders/mandelbrot.comp:147-208, shaders/julia.comp:216-249
+ * and shaders/burning_ship.comp:217-309 (z <- z^2 + c, update-then-test, smooth iteration count,
+ * palette), in fp32 (what the reference does) or fp64, plus the reference's perturbation shader
+ * (shaders/test_deep_zoom.comp).  How it is computed is MI355X-first and shares nothing with the
+ * reference's 16x16-workgroup GLSL dispatch:
  *
- *   - TILE PASS (tile_kernel): one wavefront lane per pixel; a wave owns a "sub-tile" of 64
- *     pixels (8x8, 16x4 or 64x1 -- every lane row is a whole number of 128-byte lines of the
- *     row-major RGBA-f32 frame, so stores are full-line coalesced).  A PERSISTENT grid pulls runs
- *     of sub-tiles from a tile queue sharded per XCD (8 heads, 128 B apart), stealing from the
- *     other shards when the home shard is dry; the next dequeue is issued before the current run
- *     is iterated.
- *   - STAGES.  Sub-tile cost varies 100x (a few iterations outside the set, max_iter inside) and a
- *     64-pixel wave runs as long as its slowest lane (25 % lane occupancy on a Julia dust).  So the
- *     tile pass only runs the first S0 iterations; pixels still alive are COMPACTED -- through a
- *     per-wave LDS ring into dense blocks of 64 survivor records {pixel, z, c} in HBM -- and a
- *     STREAM PASS (stream_kernel) continues them, 64 live lanes per wave, up to the next budget
- *     (x4 per stage), compacting again, until max_iter.  Every stage's work items have bounded,
- *     similar cost: long latency-hiding runs are safe in the cheap tile pass, the expensive passes
- *     are dense and balance by count.
+ *   - TILE PASS (tile_kernel): one wavefront lane per pixel; a wave owns a "sub-tile" of 64 pixels
+ *     (8x8, 16x4 or 64x1 -- every lane row is a whole number of 128-byte lines of the row-major
+ *     RGBA-f32 frame, so stores are full-line coalesced).  A PERSISTENT grid pulls runs of sub-tiles
+ *     from a queue of 8 shards (heads 128 B apart, home shard = XCD); it runs only the first b0
+ *     iterations of every pixel.  Pixels that escaped are shaded and stored; pixels still alive are
+ *     COMPACTED -- through a per-wave LDS ring into dense blocks of 64 survivor records {pixel, z, c}
+ *     in HBM, the writers rotating over 8 regions.
+ *   - LANE POOL (pool_kernel): the survivors, to max_iter.  Persistent LANES: a lane that finishes is
+ *     refilled with the next record, so waves stay full whatever the spread of escape times and the
+ *     frame balances at pixel granularity.  Sub-tile cost varies 100x (a few iterations outside the
+ *     set, max_iter inside) and a 64-pixel wave runs as long as its slowest lane (25 % lane occupancy
+ *     on a Julia dust): after the tile pass every work item has bounded cost, and the expensive
+ *     remainder runs dense.  (stream_kernel, block stages with x4 budgets, is the first form of the
+ *     second pass, kept as an option.)
  *   - the iteration index is wave-uniform and lives in SGPRs; a lane that escapes records
  *     (i, |z|^2) and is parked at the fixed point z = 0, c = 0, so no per-lane "active" predicate
- *     exists in the loop; the wave leaves the loop as soon as the ballot of finished lanes is full
- *     (wave-uniform early-out);
+ *     exists in the loop; a tile wave leaves the loop as soon as the ballot of finished lanes is full
+ *     (wave-uniform early-out); where escape is absorbing, waves run UNCHECKED blocks of 16 updates
+ *     (6 VALU ops each) with rollback + tested replay on a dirty block;
+ *   - scalar instructions share one issue port per CU: the tested loops carry a countdown and one
+ *     vector-compare branch, nothing else ("Scalar issue is a roofline too");
  *   - the arithmetic is the reference's, one rounding per operation, NO contraction of the
  *     as-written a*b+c (file is built with -ffp-contract=off).  Where an fma is written explicitly
  *     it multiplies by an exact power of two, which rounds exactly like the as-written
@@ -32,7 +36,7 @@
  *     every lane reads them from there (broadcast ds_reads).
  *
  * There is no dense contraction in this path: no MFMA.  The bound is fp64 (fp32) VALU issue; HBM
- * traffic is the write-once 16 B/pixel output plus 36 B per survivor record per stage.
+ * traffic is the write-once 16 B/pixel output plus 24-40 B per survivor record, written and read once.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -383,7 +387,8 @@ __device__ __forceinline__ uint32_t xcc_id()
 /* ---- XCD-sharded work queue ------------------------------------------------------------------
  * 8 heads, one per XCD.  A wave claims a run of items from its home shard with one atomicAdd,
  * run length clamp(remaining >> run_shift, run_min, run_max); when a shard is dry it moves to
- * the next one and returns false after all 8 were found dry (every wave reaches that).  With
+ * the next one and returns false after `max_tries` shards (all 8 by default) were found dry -- every
+ * wave reaches that.  With
  * kQueuePrefetch the next claim is issued when a run is handed out, so its latency hides under the
  * run's arithmetic (at the price of committing the wave to one more run). */
 struct WaveQueue {
