@@ -769,3 +769,28 @@ def test_randomised_views_match_the_oracle(fr, renderer, oracle):
             check_against(p, ref.iter[rows], ref.nu[rows], ref.rgba[rows], rgba, nu, it)
         except AssertionError as e:
             raise AssertionError("trial %d %r %dx%d shard %r: %s" % (trial, kw, W, H, shard, e))
+
+
+def test_contexts_release_their_device_memory(fr):
+    """Create / render / destroy cycles must give the device memory back (survivor streams, control
+    blocks, orbit and frame buffers are all context-owned)."""
+    import torch
+    torch.cuda.synchronize()
+    st = fr.FractalState(max_iterations=600)
+    out = torch.empty((512, 512, 4), dtype=torch.float32, device="cuda:0")
+
+    def cycle():
+        r = fr.Renderer(0)
+        r.render(st, 512, 512, rgba=out)
+        r.render(fr.FractalState(max_iterations=500, zoom=1e-4, use_perturbation=True), 256, 256,
+                 fractal_type=fr.FractalType.Deep_Zoom, precision=fr.Precision.F32, rgba=out[:128].reshape(256, 256, 4)[:256])
+        r.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), "leaked %d bytes over 20 create/destroy cycles" % (free0 - free1)
