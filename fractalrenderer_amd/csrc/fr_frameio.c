@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -33,33 +34,169 @@ static int write_chunk(FILE* f, const char type[4], const uint8_t* data, uint32_
     return fwrite(tail, 1, 4, f) == 4;
 }
 
+/* ---- parallel deflate -----------------------------------------------------------------------------------
+ * After the render takes < 1 ms the deflate IS the frame time of an animation export (SURVEY.md section 8 f3:
+ * an 8192x8192 RGB8 frame is 201 MB through a single-threaded zlib).  The image is cut into bands of ~1 MiB of
+ * filtered rows; worker threads compress the bands independently as RAW deflate, every band but the last ending
+ * on a sync flush (byte aligned, BFINAL = 0), the last one finishing the stream -- concatenated they are ONE valid
+ * deflate stream (what pigz does).  Each band becomes its own IDAT chunk (consecutive IDAT chunks concatenate),
+ * the zlib header rides in front of the first, the Adler-32 of the whole (combined from the bands') in a final
+ * 4-byte one.  The band partition depends on the image size only, never on the thread count, so the file is
+ * byte-identical on every machine. */
+typedef struct png_band {
+    uint32_t y0, y1;
+    uint8_t* out;          /* 4 B length + "IDAT" + [2 B zlib header] + deflate + 4 B CRC, ready to write */
+    size_t out_len;
+    uLong adler;           /* of the band's filtered bytes */
+    size_t raw_len;
+    int ok;
+} png_band;
+
+typedef struct png_job {
+    const void* rgb;
+    uint32_t width;
+    int bit_depth, level;
+    size_t row;            /* bytes of one row of samples */
+    png_band* bands;
+    uint32_t nbands;
+    volatile uint32_t next;
+} png_job;
+
+static void png_compress_band(png_job* j, uint32_t b)
+{
+    png_band* d = &j->bands[b];
+    const size_t rows = d->y1 - d->y0, raw_len = (j->row + 1) * rows;
+    d->ok = 0; d->out = NULL; d->raw_len = raw_len;
+    uint8_t* raw = (uint8_t*)malloc(raw_len);
+    if (!raw) return;
+    for (uint32_t y = d->y0; y < d->y1; ++y) {
+        uint8_t* dst = raw + (j->row + 1) * (y - d->y0);
+        *dst++ = 0;                                               /* filter type 0 (None) */
+        if (j->bit_depth == 8) memcpy(dst, (const uint8_t*)j->rgb + j->row * y, j->row);
+        else {                                                    /* PNG samples are big-endian (png_set_swap, :2198) */
+            const uint16_t* s = (const uint16_t*)j->rgb + (size_t)j->width * 3 * y;
+            for (size_t k = 0; k < (size_t)j->width * 3; ++k) { dst[2 * k] = (uint8_t)(s[k] >> 8); dst[2 * k + 1] = (uint8_t)s[k]; }
+        }
+    }
+    {   /* adler32 takes a uInt length: feed it in pieces */
+        uLong a = adler32(0L, Z_NULL, 0);
+        size_t off = 0;
+        while (off < raw_len) { const size_t n = raw_len - off > (1u << 30) ? (1u << 30) : raw_len - off; a = adler32(a, raw + off, (uInt)n); off += n; }
+        d->adler = a;
+    }
+    const int first = b == 0, last = b + 1 == j->nbands;
+    const size_t bound = compressBound((uLong)raw_len) + 64;
+    uint8_t* out = (uint8_t*)malloc(8 + 2 + bound + 4);
+    if (!out) { free(raw); return; }
+    uint8_t* p = out + 8;
+    if (first) { *p++ = 0x78; *p++ = j->level >= 7 ? 0xDA : 0x9C; }   /* zlib header: deflate, 32 KiB window */
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, j->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { free(raw); free(out); return; }
+    size_t in_off = 0, produced = 0;
+    int rc = Z_OK;
+    for (;;) {                                                    /* avail_in / avail_out are uInt: feed in pieces */
+        if (zs.avail_in == 0 && in_off < raw_len) {
+            const size_t n = raw_len - in_off > (1u << 30) ? (1u << 30) : raw_len - in_off;
+            zs.next_in = raw + in_off; zs.avail_in = (uInt)n; in_off += n;
+        }
+        const size_t room = bound - produced;
+        zs.next_out = p + produced; zs.avail_out = (uInt)(room > (1u << 30) ? (1u << 30) : room);
+        const uInt before = zs.avail_out;
+        const int flush = in_off < raw_len ? Z_NO_FLUSH : (last ? Z_FINISH : Z_SYNC_FLUSH);
+        rc = deflate(&zs, flush);
+        produced += before - zs.avail_out;
+        if (rc == Z_STREAM_END) break;
+        if (rc != Z_OK && rc != Z_BUF_ERROR) break;
+        if (flush == Z_SYNC_FLUSH && zs.avail_in == 0 && zs.avail_out != 0) break;   /* flushed completely */
+        if (produced >= bound) { rc = Z_BUF_ERROR; break; }
+    }
+    deflateEnd(&zs);
+    free(raw);
+    if (!((last && rc == Z_STREAM_END) || (!last && rc == Z_OK))) { free(out); return; }
+    const size_t data_len = (size_t)(p - (out + 8)) + produced;
+    if (data_len > 0x7FFFFFFFu) { free(out); return; }
+    put_be32(out, (uint32_t)data_len);
+    memcpy(out + 4, "IDAT", 4);
+    uLong crc = crc32(0L, Z_NULL, 0);
+    {
+        size_t off = 4;
+        const size_t endp = 8 + data_len;
+        while (off < endp) { const size_t n = endp - off > (1u << 30) ? (1u << 30) : endp - off; crc = crc32(crc, out + off, (uInt)n); off += n; }
+    }
+    put_be32(out + 8 + data_len, (uint32_t)crc);
+    d->out = out; d->out_len = 8 + data_len + 4; d->ok = 1;
+}
+
+static void* png_worker(void* arg)
+{
+    png_job* j = (png_job*)arg;
+    for (;;) {
+        const uint32_t b = __atomic_fetch_add(&j->next, 1u, __ATOMIC_RELAXED);
+        if (b >= j->nbands) break;
+        png_compress_band(j, b);
+    }
+    return NULL;
+}
+
+static int png_threads(uint32_t nbands)
+{
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    const char* e = getenv("FR_PNG_THREADS");
+    if (e && atoi(e) > 0) n = atoi(e);
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    if ((uint32_t)n > nbands) n = (long)nbands;
+    return (int)n;
+}
+
 int fr_write_png(const char* path, uint32_t width, uint32_t height, int32_t bit_depth, const void* rgb,
                  const fr_png_text* texts, int32_t ntexts, int32_t print_metadata)
 {
     if (!path || !rgb || width == 0 || height == 0 || (bit_depth != 8 && bit_depth != 16) || ntexts < 0 || (ntexts && !texts))
         return fr_set_error(FR_ERR_INVALID_ARG, "fr_write_png: bad argument");
     const size_t bpc = (size_t)bit_depth / 8, row = (size_t)width * 3 * bpc;
-    const size_t raw_len = (row + 1) * (size_t)height;
-    uint8_t* raw = (uint8_t*)malloc(raw_len);
-    if (!raw) return fr_set_error(FR_ERR_NOMEM, "out of memory");
-    for (uint32_t y = 0; y < height; ++y) {
-        uint8_t* dst = raw + (row + 1) * y;
-        *dst++ = 0;                                               /* filter type 0 (None) */
-        if (bit_depth == 8) memcpy(dst, (const uint8_t*)rgb + row * y, row);
-        else {                                                    /* PNG samples are big-endian (png_set_swap, :2198) */
-            const uint16_t* s = (const uint16_t*)rgb + (size_t)width * 3 * y;
-            for (size_t k = 0; k < (size_t)width * 3; ++k) { dst[2 * k] = (uint8_t)(s[k] >> 8); dst[2 * k + 1] = (uint8_t)s[k]; }
-        }
+
+    /* bands of ~1 MiB of filtered rows (a function of the image size only) */
+    uint32_t band_rows = (uint32_t)(((size_t)1 << 20) / (row + 1));
+    if (band_rows < 1) band_rows = 1;
+    const uint32_t nbands = (height + band_rows - 1) / band_rows;
+    png_job job;
+    memset(&job, 0, sizeof(job));
+    job.rgb = rgb; job.width = width; job.bit_depth = bit_depth; job.row = row;
+    job.level = bit_depth == 16 ? 9 : 6;                          /* png_set_compression_level(9), :2132 */
+    job.nbands = nbands;
+    job.bands = (png_band*)calloc(nbands, sizeof(png_band));
+    if (!job.bands) return fr_set_error(FR_ERR_NOMEM, "out of memory");
+    for (uint32_t b = 0; b < nbands; ++b) {
+        job.bands[b].y0 = b * band_rows;
+        job.bands[b].y1 = (b + 1) * band_rows < height ? (b + 1) * band_rows : height;
     }
-    uLongf zlen = compressBound((uLong)raw_len);
-    uint8_t* z = (uint8_t*)malloc(zlen);
-    if (!z) { free(raw); return fr_set_error(FR_ERR_NOMEM, "out of memory"); }
-    const int level = bit_depth == 16 ? 9 : 6;                    /* png_set_compression_level(9), :2132 */
-    if (compress2(z, &zlen, raw, (uLong)raw_len, level) != Z_OK) { free(raw); free(z); return fr_set_error(FR_ERR_IO, "deflate failed"); }
-    free(raw);
+    const int nthreads = png_threads(nbands);
+    pthread_t tid[64];
+    int started = 0;
+    for (int t = 1; t < nthreads; ++t)
+        if (pthread_create(&tid[started], NULL, png_worker, &job) == 0) ++started;
+    png_worker(&job);                                             /* the calling thread works too */
+    for (int t = 0; t < started; ++t) pthread_join(tid[t], NULL);
+    int bands_ok = 1;
+    uLong adler = adler32(0L, Z_NULL, 0);
+    for (uint32_t b = 0; b < nbands; ++b) {
+        if (!job.bands[b].ok) { bands_ok = 0; continue; }
+        adler = b == 0 ? job.bands[b].adler : adler32_combine(adler, job.bands[b].adler, (z_off_t)job.bands[b].raw_len);
+    }
+    if (!bands_ok) {
+        for (uint32_t b = 0; b < nbands; ++b) free(job.bands[b].out);
+        free(job.bands);
+        return fr_set_error(FR_ERR_IO, "deflate failed");
+    }
 
     FILE* f = fopen(path, "wb");
-    if (!f) { free(z); return fr_set_error(FR_ERR_IO, "cannot open '%s' for writing: %s", path, strerror(errno)); }
+    if (!f) {
+        for (uint32_t b = 0; b < nbands; ++b) free(job.bands[b].out);
+        free(job.bands);
+        return fr_set_error(FR_ERR_IO, "cannot open '%s' for writing: %s", path, strerror(errno));
+    }
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     int ok = fwrite(sig, 1, 8, f) == 8;
     uint8_t ihdr[13];
@@ -94,9 +231,15 @@ int fr_write_png(const char* path, uint32_t width, uint32_t height, int32_t bit_
                         (uint8_t)g.tm_mday, (uint8_t)g.tm_hour, (uint8_t)g.tm_min, (uint8_t)g.tm_sec};
         ok = write_chunk(f, "tIME", t, 7);
     }
-    ok = ok && write_chunk(f, "IDAT", z, (uint32_t)zlen);
+    for (uint32_t b = 0; b < nbands; ++b) {
+        if (ok) ok = fwrite(job.bands[b].out, 1, job.bands[b].out_len, f) == job.bands[b].out_len;
+        free(job.bands[b].out);
+    }
+    free(job.bands);
+    uint8_t ad[4];
+    put_be32(ad, (uint32_t)adler);                                /* the zlib trailer, in an IDAT chunk of its own */
+    ok = ok && write_chunk(f, "IDAT", ad, 4);
     ok = ok && write_chunk(f, "IEND", NULL, 0);
-    free(z);
     if (fclose(f) != 0) ok = 0;
     if (!ok) return fr_set_error(FR_ERR_IO, "writing '%s' failed", path);
     return FR_OK;

@@ -404,7 +404,7 @@ def test_write_png_8_and_16_bit(fr, tmp_path):
     p8 = str(tmp_path / "a8.png")
     fr.write_png(p8, a8)
     px, chunks = read_png(p8)
-    assert np.array_equal(px, a8) and [c[0] for c in chunks] == ["IHDR", "IDAT", "IEND"]
+    assert np.array_equal(px, a8) and [c[0] for c in chunks] == ["IHDR", "IDAT", "IDAT", "IEND"]   # one band + the Adler-32
     a16 = rng.integers(0, 65536, (19, 31, 3), dtype=np.uint16)
     p16 = str(tmp_path / "a16.png")
     fr.write_png(p16, a16, texts={"Software": "fractalrenderer_amd", "Center": "(-0.5, 0.0)", "Iterations": "1024"},
@@ -412,7 +412,7 @@ def test_write_png_8_and_16_bit(fr, tmp_path):
     px, chunks = read_png(p16)
     assert np.array_equal(px, a16)
     names = [c[0] for c in chunks]
-    assert names == ["IHDR", "gAMA", "sRGB", "pHYs", "tEXt", "tEXt", "tEXt", "tIME", "IDAT", "IEND"]
+    assert names == ["IHDR", "gAMA", "sRGB", "pHYs", "tEXt", "tEXt", "tEXt", "tIME", "IDAT", "IDAT", "IEND"]
     d = dict(chunks[:4])
     assert struct.unpack(">I", d["gAMA"])[0] == 45455                       # 1/2.2 (src/vk_engine.cpp:2145)
     assert d["sRGB"] == b"\x00"                                             # perceptual intent (:2146)
@@ -423,6 +423,34 @@ def test_write_png_8_and_16_bit(fr, tmp_path):
         fr.write_png(str(tmp_path / "no" / "dir.png"), a8)
     with pytest.raises(ValueError):
         fr.write_png(p8, a8[..., :2])
+
+
+def test_write_png_parallel_bands(fr, tmp_path, monkeypatch):
+    """Bands of ~1 MiB are deflated by worker threads and concatenated into one zlib stream (one IDAT chunk per
+    band + one for the Adler-32); the partition depends on the image size only, so the bytes do not depend on
+    the number of threads."""
+    from pngdec import read_png
+    rng = np.random.default_rng(5)
+    # smooth-ish content (compressible) with noise, 5 bands of 499 rows + a partial one
+    y, x = np.mgrid[0:2600, 0:700]
+    img = np.stack([(x + y) % 256, (x * 3 + rng.integers(0, 8, x.shape)) % 256, (y // 3) % 256], axis=-1).astype(np.uint8)
+    paths = []
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("FR_PNG_THREADS", threads)
+        p = str(tmp_path / ("t%s.png" % threads))
+        fr.write_png(p, img)
+        paths.append(p)
+    blobs = [open(p, "rb").read() for p in paths]
+    assert blobs[0] == blobs[1] == blobs[2]
+    px, chunks = read_png(paths[0])
+    assert np.array_equal(px, img)
+    assert [c[0] for c in chunks].count("IDAT") == 6 + 1 and len(chunks[-2][1]) == 4
+    assert len(blobs[0]) < img.nbytes * 4 // 5                                # it does compress (one channel is noisy)
+    wide = rng.integers(0, 65536, (3, 200000, 3), dtype=np.uint16)            # rows longer than a band: one row per band
+    pw = str(tmp_path / "wide.png")
+    fr.write_png(pw, wide)
+    px, chunks = read_png(pw)
+    assert np.array_equal(px, wide) and [c[0] for c in chunks].count("IDAT") == 3 + 1
 
 
 def test_frame_naming_and_raw_pipe(fr):
