@@ -404,6 +404,9 @@ def export_animation(anim, renderers, output_folder: str, *, fractal_type=None, 
                     post_chain=True, stream=torch.cuda.current_stream().cuda_stream)
 
     written: List[str] = []
+    # the PNG writer deflates on worker threads: share the host's cores between the ranks of the node
+    import os as _os
+    _os.environ.setdefault("FR_PNG_THREADS", str(max(1, (_os.cpu_count() or 1) // max(1, fx.world))))
 
     def finish(slot):
         fx.wait(slot)
