@@ -60,6 +60,7 @@ FP32_VALU_PEAK_TOPS = 78.6     # 157.3 TFLOP/s / 2
 
 def cpu_baseline(workload: dict) -> dict:
     """Oracle timed on the host cores on evenly spaced row bands of the same frame."""
+    import numpy as np
     from oracle import oracle as O
     O.build()
     w = workload
@@ -89,7 +90,15 @@ def cpu_baseline(workload: dict) -> dict:
                 break
     except OSError:
         pass
+    # the reference's only fp64 z <- z^2 + c (DeepZoomManager::compute_reference_orbit, src/deep_zoom_system.cpp:378-424,
+    # which prints this rate itself, :356-359): the restated loop at an interior point, one thread
+    n_orbit = 1 << 22
+    buf = np.zeros((n_orbit, 2), np.float64)
+    t1 = time.perf_counter()
+    got = O.lib().fro_reference_orbit(-0.5, 0.0, n_orbit, buf.ctypes.data)
+    orbit_rate = got / (time.perf_counter() - t1)
     return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "reference_orbit_iterations_per_s": round(orbit_rate, 0),
             "sample": f"{passes} passes over {bands} evenly spaced bands of {band_rows} rows ({px // passes} of {W*H} pixels) of the same frame, "
                       f"oracle/fr_oracle.c -O2 -ffp-contract=off, OpenMP schedule(dynamic,1), {dt:.1f} s",
             "cpu": cpu, "nproc": os.cpu_count()}
