@@ -241,6 +241,7 @@ def main() -> None:
         barrier()
         dt = time.perf_counter() - t0
         last_ms = r.last_kernel_ms()
+        lane_ms = [c.last_kernel_ms() for c in ctxs]     # device time of each render context's last launch
 
     # MAX over ranks
     if world > 1:
@@ -280,6 +281,19 @@ def main() -> None:
                                     "mean_iterations_per_pixel": round(executed / (W * H), 2)}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(w)
+        else:
+            # one launch = this rank's 1/N share of a frame (nu payload: 8 or 4 B/pixel; colour payload: 16);
+            # duration = the library's event pair around the last launch of each render context on rank 0
+            # (the lanes run concurrently, so a launch lasts longer than its share of the group time)
+            ms = [m for m in lane_ms if m > 0]
+            bpp = 16 if payload == "rgba" else (8 if prec == fr.Precision.F64 else 4)
+            bytes_per_launch = bpp * W * fx.rows_local
+            gbs = bytes_per_launch / (sum(ms) / len(ms) * 1e-3) / 1e9 if ms else 0.0
+            out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                               "kernel_ms": round(sum(ms) / len(ms), 4) if ms else None,
+                               "note": f"per launch of a 1/{world} frame share on rank 0 ({bpp} B/pixel, {lanes} concurrent "
+                                       "render contexts); the kernels are VALU-bound, see the N = 1 line for roofline_valu"}
         print(json.dumps(out), flush=True)
 
     if world > 1:
