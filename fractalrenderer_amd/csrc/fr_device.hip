@@ -35,7 +35,7 @@ struct fr_ctx {
     float* orbit_dev;           /* Deep_Zoom: reference orbit as float pairs */
     size_t orbit_cap;           /* capacity in scalars (2 per orbit point) */
     void* stream_buf[2];        /* ping-pong survivor streams */
-    size_t stream_bytes;
+    size_t stream_bytes[2];
     uint32_t tune_pool;         /* 0 = automatic (currently off), 1 = off, 2 = on: lane-pool kernel */
     uint32_t tune_pool_refill;  /* idle lanes that trigger a refill (0 = 32) */
     uint32_t tune_pool_evict;   /* stream pool: running lanes at or below which a dry wave evicts (0 = 32) */
@@ -596,15 +596,15 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const uint32_t cap_blocks = region_blocks * kShards;
     if (staged) {
         const size_t need = (size_t)cap_blocks * block_bytes;
-        if (need > c->stream_bytes) {
-            /* grow-only; happens on the first render of a larger geometry (not capturable) */
-            for (int k = 0; k < 2; ++k) {
-                if (c->stream_buf[k]) { (void)hipFree(c->stream_buf[k]); c->stream_buf[k] = nullptr; }
-            }
-            c->stream_bytes = 0;
-            FR_HIP_TRY(hipMalloc(&c->stream_buf[0], need));
-            FR_HIP_TRY(hipMalloc(&c->stream_buf[1], need));
-            c->stream_bytes = need;
+        /* grow-only; happens on the first render of a larger geometry (not capturable).  The default schedule
+         * (tile pass + one pool pass) writes one stream; the second buffer only exists for schedules with
+         * three or more passes (4 GB less scratch per context at 8192^2 fp64) */
+        for (int k = 0; k < (nstage > 2 ? 2 : 1); ++k) {
+            if (need <= c->stream_bytes[k]) continue;
+            if (c->stream_buf[k]) { (void)hipFree(c->stream_buf[k]); c->stream_buf[k] = nullptr; }
+            c->stream_bytes[k] = 0;
+            FR_HIP_TRY(hipMalloc(&c->stream_buf[k], need));
+            c->stream_bytes[k] = need;
         }
     }
 
