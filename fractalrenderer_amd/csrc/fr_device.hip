@@ -428,6 +428,134 @@ static bool needs_effects(const fr_params* p)
     }
 }
 
+/* ---- geometry of the tile pass ----------------------------------------------------------------------
+ * Sub-tiles of 64 pixels (2^shape wide) in blocks of 16 dealt round-robin to the 8 shards over a
+ * power-of-two padded block index space (optionally bit-reversed; blocks >= n_blk are skipped by the
+ * kernel); a persistent grid of exactly the resident set; run lengths and probe limit of the queue. */
+static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_local, int shape, bool bounded,
+                                 uint32_t* grid_out, uint32_t* waves_per_shard_out)
+{
+    const uint32_t fpw = 1u << shape, fph = 64u >> shape;
+    QueueArgs tq;
+    memset(&tq, 0, sizeof(tq));
+    tq.nsx = (W + fpw - 1) / fpw;
+    tq.nsx_shift = -1;
+    for (int b = 0; b < 31; ++b)
+        if (tq.nsx == (1u << b)) tq.nsx_shift = b;
+    const uint32_t nsy = (rows_local + fph - 1) / fph;
+    tq.n_items = tq.nsx * nsy;
+    tq.n_blk = (tq.n_items + kShardBlock - 1) / kShardBlock;
+    uint32_t bits = ceil_log2(tq.n_blk);
+    if (bits < 1) bits = 1;
+    tq.n_blk_padded = 1u << bits;
+    tq.blk_rev_shift = 32u - bits;
+
+    /* The fp64 tile kernel holds 5 workgroups of 256 threads per CU (the per-wave timeline of the diag buffer
+     * shows workgroups beyond the resident set only start when resident ones exit, and find the queue dry):
+     * launch exactly the resident set.  Measured 5 vs 4: C2 +1.9 %, C3 +5.6 %, C5 +1.7 %; 6-8 (the one-sample
+     * kernel fits 7 at 69 VGPRs) within 1 %. */
+    const uint32_t wg_per_cu = c->tune_wg_per_cu ? c->tune_wg_per_cu : 5u;
+    uint32_t grid = (uint32_t)c->compute_units * wg_per_cu;
+    const uint32_t max_grid = (tq.n_items + 3) / 4;        /* never more waves than sub-tiles */
+    if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
+    const uint32_t waves_per_shard = (grid * 4u + kShards - 1) / kShards;
+    auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
+    /* Run length of a dequeue = clamp(remaining >> run_shift, run_min, run_max).
+     *  - unbounded items (single pass, measured on C2, profiles/r01_sweep_c2.txt): sub-tile cost varies 100x,
+     *    so long runs leave a tail of waves holding several max_iter sub-tiles while single sub-tile claims
+     *    saturate the queue words (~88 dequeues/us each: a 0.44 ms floor): short runs of 2..8;
+     *  - bounded items (staged tile pass: at most b0 iterations each): long runs are safe and hide the
+     *    dequeue latency that dominates cheap sub-tiles. */
+    if (bounded) {
+        tq.run_shift = clamp_shift((int)ceil_log2(2u * waves_per_shard));
+        tq.run_max = c->tune_run_max ? c->tune_run_max : 32u;
+        tq.run_min = c->tune_run_min ? c->tune_run_min : 4u;
+    } else {
+        tq.run_shift = clamp_shift((int)ceil_log2(16u * waves_per_shard));
+        tq.run_max = c->tune_run_max ? c->tune_run_max : 8u;
+        tq.run_min = c->tune_run_min ? c->tune_run_min : 2u;
+    }
+    if (tq.run_min > tq.run_max) tq.run_min = tq.run_max;
+    /* no claim-ahead by default: measured equal or better without it on every workload */
+    tq.flags = c->tune_queue_flags ? (c->tune_queue_flags & 0x0Fu) : 0u;
+    /* Bounded items are dealt evenly to the shards, so a wave whose home shard is dry exits instead of
+     * probing the other 7 (measured: the exit storm of 4096 waves x 8 serialized atomics costs 31 us of the
+     * 260 us tile pass of C2 and 36 of the 74 us of a 1/8 shard, profiles/r01_probe_limit.txt).  Unbounded
+     * passes keep full stealing; so do grids with fewer workgroups than shards. */
+    uint32_t probes = c->tune_probes ? c->tune_probes : ((bounded && grid >= 64u) ? 1u : 0u);
+    if (grid < (uint32_t)kShards) probes = 0;
+    tq.flags |= probes << kQueueProbeShift;
+    *grid_out = grid;
+    *waves_per_shard_out = waves_per_shard;
+    return tq;
+}
+
+/* ---- stage schedule: iteration budgets b0 < b1 < ... < max_iter ---------------------------------------
+ * The tile pass runs [0, b0); pass k runs [b_{k-1}, b_k) (block stages, "staging" = 2) or [b0, max_iter)
+ * (lane pool, "staging" = 3, the default).  Not staged: SSAA (samples of a pixel must meet again to be
+ * averaged), the effects variants (accumulators along the whole orbit), short max_iter.  Returns the
+ * number of passes; bounds[k] = upper iteration bound of pass k. */
+static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, int bounds[kMaxStages])
+{
+    const int max_iter = p->max_iterations;
+    int nstage = 0;
+    /* automatic = tile pass + one lane-pool pass (staging 3): measured faster than the single pass on
+     * C2 (+5 %), C3 (+30 %), C5 (+40 %), 1 % slower on C4 (profiles/r01_staging_sweeps.txt) */
+    const uint32_t mode = c->tune_staging ? c->tune_staging : 3u;
+    const bool allow = !effects && p->antialiasing_samples <= 1 && (mode == 2 || mode == 3);
+    /* tile-pass budget: ~max_iter/28 rounded to the unchecked block, within [32, 192] (measured best:
+     * 32 at max_iter 1024, 64 at 2048, 128-192 at 4096, flat at 16384) */
+    int auto_first = ((max_iter / 28 + kFastBlock / 2) / kFastBlock) * kFastBlock;
+    auto_first = auto_first < 32 ? 32 : (auto_first > 192 ? 192 : auto_first);
+    const int first = c->tune_stage_first ? (int)c->tune_stage_first : auto_first;
+    const int ratio = c->tune_stage_ratio >= 2 ? (int)c->tune_stage_ratio : 4;
+    /* below ~4 budgets the second launch costs more than it balances (measured at max_iter 64: 0.32 ms
+     * staged, 0.25 ms as one bounded pass) */
+    if (allow && max_iter >= (c->tune_stage_first ? 2 : 4) * first) {
+        long long b = first - first % kFastBlock;                /* budgets are multiples of the unchecked block */
+        if (b < kFastBlock) b = kFastBlock;
+        while (b < max_iter && nstage < kMaxStages - 1) {
+            bounds[nstage++] = (int)b;
+            b *= ratio;
+            if (mode == 3) break;                                /* tile pass + lane-pool passes to max_iter */
+        }
+        /* do not leave a last stage much shorter than the one before it */
+        if (nstage >= 2 && max_iter - bounds[nstage - 1] < bounds[nstage - 1] / 4) --nstage;
+    }
+    bounds[nstage++] = max_iter;
+    if (nstage > 1 && mode == 3) {
+        /* lane-pool passes all run to max_iter; each hands the lanes it would have to run out alone (queue
+         * dry, few lanes left per wave) to the next, much smaller pass; the last runs out.  Measured:
+         * follow-up passes cost more than they save, so the default is one */
+        const int extra = c->tune_pool_passes ? (int)c->tune_pool_passes - 1 : 0;
+        for (int k = 0; k < extra && nstage < kMaxStages; ++k) bounds[nstage++] = max_iter;
+    }
+    return nstage;
+}
+
+/* Survivor streams: blocks of 64 records {pixel u32, iterations done u32, nfields x T}.  Worst case: every
+ * sample survives (npx/64 full blocks) + one partial block per writer wave; the 8 regions of a stream hold
+ * 1.5x that, so a region that fills up can spill into its neighbours.  Grow-only (happens on the first
+ * render of a larger geometry, not capturable).  The default schedule (tile pass + one pool pass) writes
+ * one stream; the second buffer only exists for schedules with three or more passes (4 GB less scratch
+ * per context at 8192^2 fp64). */
+static int reserve_streams(fr_ctx* c, size_t npx, size_t nfields, bool f64, uint32_t writer_workgroups, int nbuffers,
+                           uint32_t* region_blocks)
+{
+    const size_t block_bytes = 2 * 64 * 4 + nfields * 64 * (f64 ? 8 : 4);
+    const uint32_t worst_blocks = (uint32_t)((npx + 63) / 64) + writer_workgroups * 4u + 16u;
+    *region_blocks = (worst_blocks * 3u / 2u + kShards - 1) / kShards + 1u;
+    const size_t need = (size_t)*region_blocks * kShards * block_bytes;
+    for (int k = 0; k < nbuffers; ++k) {
+        if (need <= c->stream_bytes[k]) continue;
+        if (c->stream_buf[k]) { (void)hipFree(c->stream_buf[k]); c->stream_buf[k] = nullptr; }
+        c->stream_bytes[k] = 0;
+        FR_HIP_TRY(hipMalloc(&c->stream_buf[k], need));
+        c->stream_bytes[k] = need;
+    }
+    return FR_OK;
+}
+
 static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* shard,
                           float* rgba, void* nu, int32_t* iter, hipStream_t stream)
 {
@@ -474,44 +602,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.aspect_f = (float)W / (float)H;
     a.exact_div_ok = exact_division_ok(c, W, H, uv_map, f64) ? 1 : 0;
 
-    /* ---- stage schedule: iteration budgets b0 < b1 < ... < max_iter -------------------------------
-     * tile pass runs [0, b0), stream pass k runs [b_{k-1}, b_k).  Default b0 = 32, x4 per stage.
-     * Not staged: SSAA (samples of a pixel must meet again to be averaged), the effects variant
-     * (needs min_trap along the whole orbit), short max_iter. */
     int bounds[kMaxStages];
-    int nstage = 0;
-    {
-        /* automatic = tile pass + one lane-pool pass (staging 3): measured faster than the single pass on
-         * C2 (+5 %), C3 (+30 %), C5 (+40 %), 1 % slower on C4 (profiles/r01_staging_sweeps.txt) */
-        const uint32_t mode = c->tune_staging ? c->tune_staging : 3u;
-        const bool allow = !effects && p->antialiasing_samples <= 1 && (mode == 2 || mode == 3);
-        /* tile-pass budget: ~max_iter/28 rounded to the unchecked block, within [32, 192] (measured best:
-         * 32 at max_iter 1024, 64 at 2048, 128-192 at 4096, flat at 16384) */
-        int auto_first = ((max_iter / 28 + kFastBlock / 2) / kFastBlock) * kFastBlock;
-        auto_first = auto_first < 32 ? 32 : (auto_first > 192 ? 192 : auto_first);
-        const int first = c->tune_stage_first ? (int)c->tune_stage_first : auto_first;
-        const int ratio = c->tune_stage_ratio >= 2 ? (int)c->tune_stage_ratio : 4;
-        /* below ~4 budgets the second launch costs more than it balances (measured at max_iter 64: 0.32 ms
-         * staged, 0.25 ms as one bounded pass) */
-        if (allow && max_iter >= (c->tune_stage_first ? 2 : 4) * first) {
-            long long b = first - first % kFastBlock;            /* budgets are multiples of the unchecked block */
-            if (b < kFastBlock) b = kFastBlock;
-            while (b < max_iter && nstage < kMaxStages - 1) {
-                bounds[nstage++] = (int)b;
-                b *= ratio;
-                if (mode == 3) break;                            /* tile pass + lane-pool passes to max_iter */
-            }
-            /* do not leave a last stage much shorter than the one before it */
-            if (nstage >= 2 && max_iter - bounds[nstage - 1] < bounds[nstage - 1] / 4) --nstage;
-        }
-        bounds[nstage++] = max_iter;
-        if (nstage > 1 && mode == 3) {
-            /* lane-pool passes all run to max_iter; each hands the lanes it would have to run out alone
-             * (queue dry, few lanes left per wave) to the next, much smaller pass; the last runs out */
-            const int extra = c->tune_pool_passes ? (int)c->tune_pool_passes - 1 : 0;   /* measured: follow-up passes cost more than they save */
-            for (int k = 0; k < extra && nstage < kMaxStages; ++k) bounds[nstage++] = max_iter;
-        }
-    }
+    const int nstage = plan_stages(c, p, effects, bounds);
     const bool staged = nstage > 1;
     /* survivor-stream writers move to the next region after every block: the 8 regions come out equally
      * long with the same mix of blocks, so the reading pass is balanced with little stealing (measured,
@@ -519,93 +611,25 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const uint32_t rotate_regions = c->tune_stream_rotate == 1u ? 0u : 1u;
     const bool pool_stream = staged && (c->tune_staging ? c->tune_staging : 3u) == 3u;
 
-    /* ---- geometry of the tile pass -------------------------------------------------------------- */
-    const int shape = c->tune_shape ? (int)c->tune_shape : 3;
-    const uint32_t fpw = 1u << shape, fph = 64u >> shape;
-    QueueArgs tq;
-    memset(&tq, 0, sizeof(tq));
-    tq.nsx = (W + fpw - 1) / fpw;
-    tq.nsx_shift = -1;
-    for (int b = 0; b < 31; ++b)
-        if (tq.nsx == (1u << b)) tq.nsx_shift = b;
-    const uint32_t nsy = (rows_local + fph - 1) / fph;
-    tq.n_items = tq.nsx * nsy;
-    /* blocks of 16 sub-tiles are dealt round-robin to the 8 shards over a power-of-two padded block
-     * index space (optionally bit-reversed; blocks >= n_blk are skipped by the kernel) */
-    tq.n_blk = (tq.n_items + kShardBlock - 1) / kShardBlock;
-    uint32_t bits = ceil_log2(tq.n_blk);
-    if (bits < 1) bits = 1;
-    tq.n_blk_padded = 1u << bits;
-    tq.blk_rev_shift = 32u - bits;
-
-    /* The fp64 tile kernel holds 5 workgroups of 256 threads per CU (85 VGPRs; the per-wave timeline of
-     * the diag buffer shows workgroups beyond the resident set only start when resident ones exit, and
-     * find the queue dry): launch exactly the resident set.  Measured 5 vs 4: C2 +1.9 %, C3 +5.6 %, C5 +1.7 %;
-     * squeezing the kernel into 80 VGPRs for 6 (amdgpu_waves_per_eu(6): 8 B/lane of scratch) gains nothing. */
-    const uint32_t wg_per_cu = c->tune_wg_per_cu ? c->tune_wg_per_cu : 5u;
-    uint32_t grid = (uint32_t)c->compute_units * wg_per_cu;
-    const uint32_t max_grid = (tq.n_items + 3) / 4;        /* never more waves than sub-tiles */
-    if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
-    const uint32_t waves_per_shard = (grid * 4u + kShards - 1) / kShards;
-    auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
-    /* Run length of a dequeue = clamp(remaining >> run_shift, run_min, run_max).
-     *  - single pass (measured on C2, profiles/r01_sweep_c2.txt): sub-tile cost varies 100x, so long
-     *    runs leave a tail of waves holding several max_iter sub-tiles while single sub-tile claims
-     *    saturate the queue words (~88 dequeues/us each: a 0.44 ms floor): short runs of 2..8;
-     *  - staged tile pass: every sub-tile costs at most b0 iterations, so long runs are safe and
-     *    hide the dequeue latency that dominates cheap sub-tiles. */
     /* bounded, cheap items: the staged tile pass, and an unstaged pass whose samples run at most 128 updates
      * (measured at max_iter <= 32: 0.31 ms with short runs -- the queue words saturate -- 0.17 ms with long) */
     const int aa1 = p->antialiasing_samples > 1 ? p->antialiasing_samples : 1;
     const bool bounded = staged || (!effects && (long long)max_iter * aa1 * aa1 <= 128);
-    if (bounded) {
-        tq.run_shift = clamp_shift((int)ceil_log2(2u * waves_per_shard));
-        tq.run_max = c->tune_run_max ? c->tune_run_max : 32u;
-        tq.run_min = c->tune_run_min ? c->tune_run_min : 4u;
-    } else {
-        tq.run_shift = clamp_shift((int)ceil_log2(16u * waves_per_shard));
-        tq.run_max = c->tune_run_max ? c->tune_run_max : 8u;
-        tq.run_min = c->tune_run_min ? c->tune_run_min : 2u;
-    }
-    if (tq.run_min > tq.run_max) tq.run_min = tq.run_max;
-    /* no claim-ahead by default: measured equal or better without it on every workload */
-    tq.flags = c->tune_queue_flags ? (c->tune_queue_flags & 0x0Fu) : 0u;
-    /* Staged tile pass: sub-tiles are dealt evenly to the shards and cost at most b0 iterations each, so a
-     * wave whose home shard is dry exits instead of probing the other 7 (measured: the exit storm of
-     * 4096 waves x 8 serialized atomics costs 31 us of the 260 us tile pass of C2 and 36 of the 74 us of
-     * a 1/8 shard, profiles/r01_probe_limit.txt).  Unstaged passes keep full stealing: their items cost
-     * anything between 1 and max_iter iterations. */
-    {
-        uint32_t probes = c->tune_probes ? c->tune_probes : ((bounded && grid >= 64u) ? 1u : 0u);
-        if (grid < (uint32_t)kShards) probes = 0;          /* fewer workgroups than shards: everybody probes everything */
-        tq.flags |= probes << kQueueProbeShift;
-    }
+    const int shape = c->tune_shape ? (int)c->tune_shape : 3;
+    uint32_t grid = 0, waves_per_shard = 0;
+    const QueueArgs tq = plan_tile_queue(c, W, rows_local, shape, bounded, &grid, &waves_per_shard);
+    auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
     c->last_grid = grid;
 
-    /* ---- survivor streams (ping-pong) in context scratch ------------------------------------------ */
-    const size_t nfields = julia ? 2 : 4;
-    const size_t block_bytes = 2 * 64 * 4 + nfields * 64 * (f64 ? 8 : 4);
-    /* the stream kernel holds 6 workgroups per CU (57 VGPRs, SGPR-limited); its blocks are latency
-     * bound (dequeue -> record loads -> iterate -> scattered stores), so run all of them */
+    /* ---- survivor streams in context scratch ------------------------------------------------------------ */
+    /* the pool / stream kernels hold 6 workgroups per CU; their blocks are latency bound (dequeue -> record
+     * loads -> iterate -> scattered stores), so run all of them */
     const uint32_t sgrid = (uint32_t)c->compute_units * (c->tune_stream_wg_per_cu ? c->tune_stream_wg_per_cu : 6u);
-    const size_t npx = (size_t)rows_local * W;
-    /* worst case: every sample survives (npx/64 full blocks) + one partial block per wave; the 8
-     * regions of a stream hold 1.5x that, so a region that fills up can spill into its neighbours */
-    const uint32_t worst_blocks = (uint32_t)((npx + 63) / 64) + (grid > sgrid ? grid : sgrid) * 4u + 16u;
-    const uint32_t region_blocks = (worst_blocks * 3u / 2u + kShards - 1) / kShards + 1u;
-    const uint32_t cap_blocks = region_blocks * kShards;
+    uint32_t region_blocks = 0;
     if (staged) {
-        const size_t need = (size_t)cap_blocks * block_bytes;
-        /* grow-only; happens on the first render of a larger geometry (not capturable).  The default schedule
-         * (tile pass + one pool pass) writes one stream; the second buffer only exists for schedules with
-         * three or more passes (4 GB less scratch per context at 8192^2 fp64) */
-        for (int k = 0; k < (nstage > 2 ? 2 : 1); ++k) {
-            if (need <= c->stream_bytes[k]) continue;
-            if (c->stream_buf[k]) { (void)hipFree(c->stream_buf[k]); c->stream_buf[k] = nullptr; }
-            c->stream_bytes[k] = 0;
-            FR_HIP_TRY(hipMalloc(&c->stream_buf[k], need));
-            c->stream_bytes[k] = need;
-        }
+        const int st = reserve_streams(c, (size_t)rows_local * W, julia ? 2 : 4, f64, grid > sgrid ? grid : sgrid,
+                                       nstage > 2 ? 2 : 1, &region_blocks);
+        if (st != FR_OK) return st;
     }
 
     FR_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, kCtrlWords * sizeof(uint32_t), stream));
