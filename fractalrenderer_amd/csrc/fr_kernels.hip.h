@@ -1572,9 +1572,7 @@ deep_zoom_kernel(const DeepZoomArgs A)
             int esc_i = max_iter;
             float ezx = 0.0f, ezy = 0.0f;
             /* perturbed iteration against the reference orbit, :153-173 */
-            for (int i = 0; i < n_ref; ++i) {
-                if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
-                const float2 zr = A.orbit[i];                                            /* wave-uniform index */
+            auto perturb = [&](const float2 zr, const int i) {
                 const float mx = zr.x * dzx - zr.y * dzy, my = zr.x * dzy + zr.y * dzx;
                 const float t1x = mx * 2.0f, t1y = my * 2.0f;
                 const float t2x = dzx * dzx - dzy * dzy, t2y = 2.0f * dzx * dzy;
@@ -1584,20 +1582,36 @@ deep_zoom_kernel(const DeepZoomArgs A)
                     const float zfx = zr.x + dzx, zfy = zr.y + dzy;
                     if (zfx * zfx + zfy * zfy > bailout_sq) { live = false; esc_i = i; ezx = zfx; ezy = zfy; }
                 }
+            };
+            /* four reference points per scalar load and per "anybody still alive" test: the orbit comes through
+             * the scalar cache (wave-uniform index), whose latency would otherwise sit in every update */
+            int i = 0;
+            for (; i + 4 <= n_ref; i += 4) {
+                if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
+                const float2 z0 = A.orbit[i], z1 = A.orbit[i + 1], z2 = A.orbit[i + 2], z3 = A.orbit[i + 3];
+                perturb(z0, i); perturb(z1, i + 1); perturb(z2, i + 2); perturb(z3, i + 3);
             }
+            if (__builtin_amdgcn_ballot_w64(live) != 0ull)
+                for (; i < n_ref; ++i) perturb(A.orbit[i], i);
             /* continue in plain fp32 for the remaining iterations, :181-203 */
             float zx, zy;
             if (ref_iter > 0) { const float2 zl = A.orbit[ref_iter - 1]; zx = zl.x + dzx; zy = zl.y + dzy; }
             else { zx = c_fx; zy = c_fy; }
-            for (int i = n_ref; i < max_iter; ++i) {
-                if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
+            auto plain = [&](const int k) {
                 const float z2x = zx * zx - zy * zy, z2y = 2.0f * zx * zy;
                 const float nx = z2x + c_fx, ny = z2y + c_fy;
                 if (live) {
                     zx = nx; zy = ny;
-                    if (zx * zx + zy * zy > bailout_sq) { live = false; esc_i = i; ezx = zx; ezy = zy; }
+                    if (zx * zx + zy * zy > bailout_sq) { live = false; esc_i = k; ezx = zx; ezy = zy; }
                 }
+            };
+            int k = n_ref;
+            for (; k + 4 <= max_iter; k += 4) {
+                if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
+                plain(k); plain(k + 1); plain(k + 2); plain(k + 3);
             }
+            if (__builtin_amdgcn_ballot_w64(live) != 0ull)
+                for (; k < max_iter; ++k) plain(k);
             if (inside) {
                 float rgb[3] = {0.0f, 0.0f, 0.0f};
                 float smooth = (float)max_iter;
