@@ -794,3 +794,13 @@ def test_contexts_release_their_device_memory(fr):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), "leaked %d bytes over 20 create/destroy cycles" % (free0 - free1)
+
+
+def test_plain_c_client_renders_through_the_abi(fr, tmp_path):
+    """tests/c_client/client.c (C11, public header only, no Python / torch in the process): render to host
+    buffers, analytic known answers, conjugate symmetry, shard == rows of the frame, export, PNG, error codes."""
+    import subprocess
+    from test_host import build_c_client
+    exe = build_c_client(tmp_path)
+    out = subprocess.run([exe, "gpu", str(tmp_path / "g.png")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "gpu ok", out.stderr

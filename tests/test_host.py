@@ -465,3 +465,25 @@ def test_frame_naming_and_raw_pipe(fr):
     assert got == frame.tobytes()
     with pytest.raises(fr.FractalRendererError):
         fr.write_raw_rgb24(-1, frame)
+
+
+def build_c_client(tmp_path):
+    """gcc-compiles tests/c_client/client.c against include/fractalrenderer_amd.h and the built library."""
+    import subprocess
+    exe = str(tmp_path / "fr_client")
+    libdir = os.path.join(ROOT, "fractalrenderer_amd")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_client", "client.c"), "-o", exe,
+           "-L" + libdir, "-lfractalrenderer_amd", "-lm", "-Wl,-rpath," + libdir]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return exe
+
+
+def test_plain_c_client_host_entry_points(fr, golden, tmp_path):
+    """The boundary is a C ABI: a C11 program that only includes the public header links against the library and
+    drives the host-side entry points (params, push constants, shard arithmetic, .franim, PNG, naming)."""
+    import subprocess
+    exe = build_c_client(tmp_path)
+    out = subprocess.run([exe, "host", golden["franim"], str(tmp_path / "c.png")], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "host ok", out.stderr
