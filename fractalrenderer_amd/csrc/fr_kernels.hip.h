@@ -635,10 +635,14 @@ __device__ __forceinline__ void orbit_step(Orbit<T>& o)
     o.y2d = o.Yd * o.Yd;
 }
 
+/* 4 |z|^2 = RN(4 x2 + y2d): the escape test compares it with 4 B^2.  Scaling by a power of two commutes
+ * with rounding, so this is exactly 4 * RN(zx^2 + zy^2) and the test is the as-written one; written this
+ * way the multiplier 4.0 is an inline constant of a three-operand v_fma_f64 (0.25 is not: the compiler
+ * needed a register copy + v_fmac with a literal, one more instruction per tested update). */
 template <typename T>
-__device__ __forceinline__ T orbit_r2(const Orbit<T>& o)
+__device__ __forceinline__ T orbit_r2x4(const Orbit<T>& o)
 {
-    return Real<T>::fma(T(0.25), o.y2d, o.x2);
+    return Real<T>::fma(T(4), o.x2, o.y2d);
 }
 
 /* Runs the wave's 64 orbits over iterations [i0, i1).  esc_i: escape index, i1 if the lane is
@@ -651,6 +655,7 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
 {
     esc_i = i1;
     esc_r2 = T(0);
+    const T B2x4 = T(4) * B2;
     uint64_t done = done_in;
     int i = i0;                      /* wave-uniform: SGPR */
     bool fast = start_fast && fast_ok;
@@ -662,8 +667,7 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
             const Orbit<T> snap = o;
 #pragma unroll
             for (int k = 0; k < kFastBlock; ++k) orbit_step<T, ABS>(o);
-            const T r2 = orbit_r2(o);
-            const bool bad = !(r2 <= B2);
+            const bool bad = !(orbit_r2x4(o) <= B2x4);
             if (__builtin_amdgcn_ballot_w64(bad) == 0ull) { i += kFastBlock; continue; }
             o = snap;                /* roll back, replay tested */
             fast = false;
@@ -674,13 +678,13 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
         const uint64_t before = done;
         do {
             orbit_step<T, ABS>(o);
-            const T r2 = orbit_r2(o);
-            const bool e = r2 > B2;
+            const T r2x4 = orbit_r2x4(o);
+            const bool e = r2x4 > B2x4;
             const uint64_t em = __builtin_amdgcn_ballot_w64(e);
             if (em != 0ull) {
                 if (e) {
                     esc_i = i;
-                    esc_r2 = r2;
+                    esc_r2 = T(0.25) * r2x4;
                     /* park at the fixed point z = 0 of c = 0: never "escapes" again */
                     o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
                 }
@@ -1186,6 +1190,7 @@ pool_kernel(const LaunchArgs A)
     const T center_x = (T)S.center_x, center_y = (T)S.center_y, zoom = (T)S.zoom;
     const T bailout = (T)S.bailout;
     const T B2 = bailout * bailout;
+    const T B2x4 = T(4) * B2;
     const T resx = (T)W, resy = (T)H;
     const T inv_w = sizeof(T) == 8 ? (T)A.inv_w_d : (T)A.inv_w_f;
     const T inv_h = sizeof(T) == 8 ? (T)A.inv_h_d : (T)A.inv_h_f;
@@ -1408,8 +1413,7 @@ pool_kernel(const LaunchArgs A)
 #pragma unroll
                     for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
                 }
-                const T r2 = orbit_r2(o);
-                if (__builtin_amdgcn_ballot_w64(!(r2 <= B2)) == 0ull) {
+                if (__builtin_amdgcn_ballot_w64(!(orbit_r2x4(o) <= B2x4)) == 0ull) {
                     wclock += reps * (uint32_t)kFastBlock;
                     ++streak;
                     /* clean block: lanes at or past their deadline never escaped -> interior */
@@ -1431,14 +1435,14 @@ pool_kernel(const LaunchArgs A)
             bool escaped = false;
             do {
                 orbit_step<T, Form<FRACTAL>::abs_step>(o);
-                const T r2 = orbit_r2(o);
-                const bool e = r2 > B2;
+                const T r2x4 = orbit_r2x4(o);
+                const bool e = r2x4 > B2x4;
                 const uint64_t em = __builtin_amdgcn_ballot_w64(e);
                 ++k;
                 if (em != 0ull) {
                     if (e) {
                         esc_i = (int)(wclock + k - 1u - (deadline - (uint32_t)max_iter));
-                        esc_r2 = r2;
+                        esc_r2 = T(0.25) * r2x4;
                         fin = 1u;
                         o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
                     }
