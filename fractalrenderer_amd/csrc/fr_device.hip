@@ -54,7 +54,6 @@ struct fr_ctx {
     uint32_t tune_probes;       /* tile pass: shards a wave probes before exiting (0 = automatic) */
     uint32_t tune_stream_probes;/* same for the stream / lane-pool passes */
     uint32_t tune_stream_rotate;/* 0 automatic, 1 regions by XCD, 2 writers rotate over the regions */
-    uint32_t tune_stream_records;/* 0 automatic, 1 the pool claims blocks, 2 it claims exactly the records its idle lanes need */
     uint64_t* diag;             /* optional device buffer for per-wave timelines */
     uint32_t last_grid;
     uint32_t tune_shape;        /* 0 = automatic, else FPW_LOG2 (3, 4, 6) */
@@ -186,8 +185,6 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         c->tune_stream_probes = (uint32_t)value & 0xFu;
     } else if (!strcmp(name, "stream_rotate")) {
         c->tune_stream_rotate = (uint32_t)value;
-    } else if (!strcmp(name, "stream_records")) {
-        c->tune_stream_records = (uint32_t)value;
     } else if (!strcmp(name, "diag_buffer")) {
         c->diag = (uint64_t*)(uintptr_t)value;        /* device pointer, 4 x u64 per wave of the grid; 0 = off */
     } else {
@@ -708,7 +705,6 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
             a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 1u;
             a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 2u;
             a.q.flags &= ~kQueuePrefetch;
-            if (c->tune_stream_records == 2u) a.q.flags |= kQueueRecords;
             if (k >= 2) {
                 /* follow-up passes read the partial blocks evicted by the previous pass (a few lanes per
                  * block): claim several per dequeue so that the records fill whole waves */

@@ -56,7 +56,6 @@ constexpr int kShardBlock = 16;          /* sub-tiles are dealt to shards in blo
 constexpr int kFastBlock = 16;           /* iterations per unchecked block                 */
 constexpr uint32_t kQueueScatter = 1u;   /* bit-reversed block order                       */
 constexpr uint32_t kQueuePrefetch = 2u;  /* issue the next dequeue before iterating the current run */
-constexpr uint32_t kQueueRecords = 8u;   /* lane pool over a stream: claim exactly the records the idle lanes need */
 constexpr uint32_t kQueueProbeShift = 4; /* bits 4-7: shards a wave may probe before giving up (0 = all 8) */
 constexpr uint32_t kInvalidPixel = 0xFFFFFFFFu;
 constexpr int kRingSlots = 128;          /* survivor ring capacity per wave (records)      */
@@ -396,7 +395,6 @@ struct WaveQueue {
     uint32_t n_groups, group;     /* groups dealt round-robin: shard k owns groups k, k+8, ... of `group` items */
     const uint32_t* len_words;    /* or: per-shard lengths in memory (kShardStrideWords apart), capped at len_cap */
     uint32_t len_cap;
-    uint32_t len_mul;             /* 1, or 64 when the heads count records of 64-record blocks */
     uint32_t run_shift, run_min, run_max;
     uint32_t lane;
     uint32_t shard, tried, seen, max_tries;
@@ -407,7 +405,7 @@ struct WaveQueue {
     {
         if (len_words) {
             const uint32_t v = len_words[sh * kShardStrideWords];      /* uniform address: scalar load */
-            return (v < len_cap ? v : len_cap) * len_mul;
+            return v < len_cap ? v : len_cap;
         }
         return ((n_groups + (uint32_t)kShards - 1u - sh) / (uint32_t)kShards) * group;
     }
@@ -429,7 +427,7 @@ struct WaveQueue {
                                          uint32_t rmin, uint32_t rmax, bool pf, uint32_t ln)
     {
         heads = h;
-        n_groups = groups; group = group_items; len_words = nullptr; len_cap = 0; len_mul = 1;
+        n_groups = groups; group = group_items; len_words = nullptr; len_cap = 0;
         run_shift = shift; run_min = rmin; run_max = rmax; prefetch = pf; lane = ln;
         shard = xcc_id(); tried = 0; seen = 0; max_tries = (uint32_t)kShards;
         cur_n = cur_raw = next_n = next_raw = 0;
@@ -453,25 +451,6 @@ struct WaveQueue {
          * XCD placement is: take the home from the workgroup index (identical to the XCD id under the
          * usual round-robin dispatch).  The host only limits probing on grids of >= 64 workgroups. */
         shard = blockIdx.x & (uint32_t)(kShards - 1);
-    }
-    /* Record-granular claim (heads count records): exactly the `want` records the idle lanes can start now
-     * (fewer at the end of a shard), so that no record waits in a reserve.  false = no work left anywhere. */
-    __device__ __forceinline__ bool take(uint32_t want, uint32_t& begin, uint32_t& count, uint32_t& sh)
-    {
-        for (;;) {
-            while (shard_len(shard) == 0u) {
-                if (++tried >= max_tries) return false;
-                shard = (shard + 1u) & (uint32_t)(kShards - 1);
-            }
-            const uint32_t b = __builtin_amdgcn_readfirstlane(claim(shard, want));
-            const uint32_t l = shard_len(shard);
-            if (b < l) {
-                begin = b; count = want < l - b ? want : l - b; sh = shard;
-                return true;
-            }
-            if (++tried >= max_tries) return false;
-            shard = (shard + 1u) & (uint32_t)(kShards - 1);
-        }
     }
     /* hands out the next run [begin, begin+count) of shard `sh`; false = no work left anywhere */
     __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& count, uint32_t& sh)
@@ -1235,9 +1214,7 @@ pool_kernel(const LaunchArgs A)
     uint32_t wclock = 0;
     uint32_t next_deadline = 0;          /* a lower bound of the earliest deadline among running lanes */
     bool have_running = false;
-    uint32_t res_begin = 0, res_count = 0, res_shard = 0, res_next = 0;    /* reserve: items [res_begin, res_begin + res_count) of a shard, cursor res_next */
-    const bool by_records = FROM_STREAM && (A.q.flags & kQueueRecords) != 0;
-    if (by_records) q.len_mul = 64u;
+    uint32_t res_begin = 0, res_count = 0, res_shard = 0, res_next = 0;    /* reserve: run of 64-item groups, cursor in items */
     bool dry = false, fast = false;
 
     for (;;) {
@@ -1260,16 +1237,8 @@ pool_kernel(const LaunchArgs A)
         for (;;) {
             const uint64_t freem = __builtin_amdgcn_ballot_w64(pixel == kInvalidPixel);
             if (freem == 0ull || dry) break;
-            const uint32_t nfree = (uint32_t)__builtin_popcountll(freem);
-            if (res_next == res_count) {
-                /* by_records ("stream_records" = 2, an experiment kept as an option): no reserve at all -- a claimed
-                 * record starts at once.  Measured: the waves' finish times bunch up (p1..p99 of "queue found dry"
-                 * 84 us instead of 145 us on C2) but the pass ends at the same time; C2 +2 %, C3 -15 % (an atomic
-                 * per refill on escape-dense records), C5 -1 %; mixtures with block claims are no better than blocks. */
-                bool got;
-                if (by_records) got = q.take(nfree, res_begin, res_count, res_shard);
-                else { got = q.next(res_begin, res_count, res_shard); res_begin *= 64u; res_count *= 64u; }
-                if (!got) {
+            if (res_next == res_count * 64u) {
+                if (!q.next(res_begin, res_count, res_shard)) {
                     dry = true;
                     /* diagnostics: when this wave found the queue dry, in 100 MHz ticks since its start (bits 32..) */
                     diag_dry = A.diag ? (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0) : 0u;
@@ -1277,15 +1246,16 @@ pool_kernel(const LaunchArgs A)
                 }
                 res_next = 0;
                 ++diag_claims;
-                diag_items += by_records ? res_count : res_count >> 6;
+                diag_items += res_count;
             }
-            const uint32_t avail = res_count - res_next;
+            const uint32_t nfree = (uint32_t)__builtin_popcountll(freem);
+            const uint32_t avail = res_count * 64u - res_next;
             const uint32_t n = nfree < avail ? nfree : avail;
             if (pixel == kInvalidPixel) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freem, 0u));
                 if (rank < n) {
-                    const uint32_t t = res_begin + res_next + rank;
-                    const uint32_t j = t >> 6, l = t & 63u;
+                    const uint32_t t = res_next + rank;
+                    const uint32_t j = res_begin + (t >> 6), l = t & 63u;
                     if constexpr (FROM_STREAM) {
                         /* record l of block j of region res_shard */
                         const uint8_t* b = A.in.base + ((size_t)res_shard * A.in.region_blocks + j) * kBlockBytes;

@@ -218,8 +218,6 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                        (1..8; 0 = automatic: 1 for a staged tile pass, 4 for its stream passes, 8 otherwise)
  *   "stream_rotate"      2 = survivor-stream writers rotate over the 8 regions (equal regions), 1 = one region
  *                        per XCD, 0 = automatic (= 2)
- *   "stream_records"     2 = the lane pool claims exactly the records its idle lanes need (no reserve),
- *                        1 = it claims whole blocks, 0 = automatic (= 1)
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1
  *   "diag_buffer"        device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks,
  *                        items processed, dequeues); 0 disables.  "diag_stride" = uint64 words

@@ -169,7 +169,7 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
     base = gpu_render(fr, renderer, p, 200, 120)
     assert renderer.last_stages() == 2                     # default: tile pass + lane-pool pass
     opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "queue_flags", "stream_workgroups_per_cu", "pool_refill_at", "pool_passes", "pool_evict_at",
-            "probes", "stream_probes", "stream_rotate", "stream_records")
+            "probes", "stream_probes", "stream_rotate")
     try:
         for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
             renderer.set_tuning(wg, run, shape)
@@ -183,8 +183,7 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
                    dict(probes=8), dict(probes=2), dict(probes=1, stream_probes=1), dict(staging=1, probes=1),
                    dict(staging=2, probes=3, stream_probes=2), dict(stream_rotate=1), dict(stream_rotate=1, stream_probes=1),
                    dict(stream_rotate=2, stream_probes=8), dict(staging=2, stream_rotate=1),
-                   dict(stream_records=2), dict(stream_records=2, pool_refill_at=1), dict(stream_records=2, pool_refill_at=64, stream_probes=1),
-                   dict(stream_records=2, pool_passes=3, pool_evict_at=40), dict(stream_records=1),
+
                    dict(staging=2, stage_first=16, stage_ratio=2, queue_flags=0x101, stream_workgroups_per_cu=2),
                    dict(staging=3), dict(staging=3, stage_first=64, pool_refill_at=8), dict(staging=3, stage_first=16, pool_refill_at=64),
                    dict(staging=3, stream_run_max=1, stream_workgroups_per_cu=1), dict(staging=3, pool_passes=1),

@@ -13,7 +13,7 @@ rng = np.random.default_rng(seed)
 r = fr.Renderer(0)
 anchors = {0: [(-0.743643887037151, 0.13182590420533), (-0.1011, 0.9563), (-1.25066, 0.02012), (0.275, 0.0), (-0.5, 0.0), (-1.7497, 0.00001)],
            1: [(0.0, 0.0), (0.3, 0.2), (-0.6, 0.1)], 2: [(-1.755, -0.03), (-0.5, -0.5), (-1.62, -0.002)]}
-opts = ["staging", "pool_refill_at", "stream_records", "probes", "stream_probes", "stream_rotate", "stage_first", "subtile_shape", "workgroups_per_cu"]
+opts = ["staging", "pool_refill_at", "probes", "stream_probes", "stream_rotate", "stage_first", "subtile_shape", "workgroups_per_cu"]
 bad = 0
 for trial in range(trials):
     fractal = int(rng.integers(0, 3)); prec = int(rng.integers(0, 2))
@@ -31,7 +31,7 @@ for trial in range(trials):
     ref = oracle.render(p, W, H)
     tune = {}
     if trial % 2:
-        tune = {"staging": int(rng.choice([0, 1, 2, 3])), "pool_refill_at": int(rng.choice([0, 1, 8, 40, 64])), "stream_records": int(rng.choice([0, 2])),
+        tune = {"staging": int(rng.choice([0, 1, 2, 3])), "pool_refill_at": int(rng.choice([0, 1, 8, 40, 64])),
                 "probes": int(rng.choice([0, 1, 2, 8])), "stream_probes": int(rng.choice([0, 1, 4, 8])), "stream_rotate": int(rng.choice([0, 1, 2])),
                 "stage_first": int(rng.choice([0, 16, 48, 160])), "subtile_shape": int(rng.choice([0, 3, 4, 6])), "workgroups_per_cu": int(rng.choice([0, 1, 3, 7]))}
     for k in opts: r.set_option(k, tune.get(k, 0))
