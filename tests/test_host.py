@@ -487,3 +487,42 @@ def test_plain_c_client_host_entry_points(fr, golden, tmp_path):
     exe = build_c_client(tmp_path)
     out = subprocess.run([exe, "host", golden["franim"], str(tmp_path / "c.png")], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "host ok", out.stderr
+
+
+def test_hot_kernels_keep_their_register_budget(fr):
+    """The launcher sizes its persistent grids for a resident set (tile pass 5, lane pool 6 workgroups of 4 waves per
+    CU): a change that pushes a hot kernel over its VGPR budget silently leaves workgroups non-resident (an
+    experimental option once cost the lane pool 12 VGPRs and 34 SGPR spills: -5 % to -13 % on every workload).
+    Recompiles the device code with resource remarks and checks the kernels the defaults launch."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "fractalrenderer_amd", "csrc")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                          "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-c", os.path.join(csrc, "fr_device.hip"),
+                          "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    usage = {}
+    cur = None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = usage.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|SGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    budget = {   # mangled name: (max VGPRs, min waves/SIMD, max SGPR spills)
+        "_ZN2fr11pool_kernelIdLi0ELi3ELb1EEEvNS_10LaunchArgsE": (80, 6, 16),       # fp64 Mandelbrot lane pool (C2/C4/C5)
+        "_ZN2fr11pool_kernelIfLi1ELi3ELb1EEEvNS_10LaunchArgsE": (64, 6, 8),        # fp32 Julia lane pool (C3)
+        "_ZN2fr11tile_kernelIdLi0ELi3ELb0ELb0EEEvNS_10LaunchArgsE": (96, 5, 48),   # fp64 Mandelbrot tile pass
+        "_ZN2fr11tile_kernelIfLi1ELi3ELb0ELb0EEEvNS_10LaunchArgsE": (64, 5, 24),   # fp32 Julia tile pass
+    }
+    for name, (max_vgpr, min_occ, max_spill) in budget.items():
+        u = usage.get(name)
+        assert u, "kernel %s not found in the resource remarks" % name
+        assert u["ScratchSize [bytes/lane]"] == 0, (name, u)
+        assert u["VGPRs"] <= max_vgpr and u["Occupancy [waves/SIMD]"] >= min_occ and u["SGPRs Spill"] <= max_spill, (name, u)
