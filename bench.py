@@ -122,6 +122,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="N = 1: after the timed region, also time the same K steps with two frames in flight "
+                         "(informational `pipelined` object; off by default so that a rocprofv3 trace of the "
+                         "default command only contains the one-frame-at-a-time launches the roofline is quoted on)")
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--run-max", type=int, default=0)
     ap.add_argument("--shape", type=int, default=0)
@@ -209,26 +213,28 @@ def main() -> None:
         # the phase boundaries of a frame (tile-pass tail, launch gaps, pool-pass drain) with the other frame's
         # work.  NOT the headline `value`: that stays one frame at a time, so that `roofline` keeps its
         # per-launch meaning and agrees with the rocprofv3 kernel durations.
-        r2 = fr.Renderer(local_rank)
-        r2.set_tuning(args.wg_per_cu, args.run_max, args.shape)
-        rgba2 = torch.empty_like(rgba)
-        stream2 = torch.cuda.Stream(device=dev)
-        pair = ((r, rgba, h), (r2, rgba2, stream2.cuda_stream))
+        dt_pipe = None
+        if args.pipelined:
+            r2 = fr.Renderer(local_rank)
+            r2.set_tuning(args.wg_per_cu, args.run_max, args.shape)
+            rgba2 = torch.empty_like(rgba)
+            stream2 = torch.cuda.Stream(device=dev)
+            pair = ((r, rgba, h), (r2, rgba2, stream2.cuda_stream))
 
-        def step2(k):
-            rr, buf, hh = pair[k & 1]
-            rr.render(state, W, H, fractal_type=ftype, precision=prec, rgba=buf, sync=False, stream=hh)
+            def step2(k):
+                rr, buf, hh = pair[k & 1]
+                rr.render(state, W, H, fractal_type=ftype, precision=prec, rgba=buf, sync=False, stream=hh)
 
-        for k in range(max(2, args.warmup)):
-            step2(k)
-        barrier()
-        t0p = time.perf_counter()
-        for k in range(args.steps):
-            step2(k)
-        barrier()
-        dt_pipe = time.perf_counter() - t0p
-        r2.close()
-        del rgba2
+            for k in range(max(2, args.warmup)):
+                step2(k)
+            barrier()
+            t0p = time.perf_counter()
+            for k in range(args.steps):
+                step2(k)
+            barrier()
+            dt_pipe = time.perf_counter() - t0p
+            r2.close()
+            del rgba2
     else:
         payload = args.payload
         if payload == "auto":
@@ -305,11 +311,12 @@ def main() -> None:
                                     "unit": "Tflop/s (8 flop per executed iteration, no FMA credit)",
                                     "frac": round(tops / peak, 4), "executed_iterations": executed,
                                     "mean_iterations_per_pixel": round(executed / (W * H), 2)}
-            out["pipelined"] = {"frames_in_flight": 2, "value": round(args.steps * W * H / dt_pipe / 1e6, 2), "unit": "Mpixels/s",
-                                "ms_per_step": round(dt_pipe / args.steps * 1e3, 4),
-                                "valu_frac": round(8.0 * executed / (dt_pipe / args.steps) / 1e12 / peak, 4),
-                                "note": "informational: two render contexts on two streams, frames alternating; "
-                                        "the headline value above runs one frame at a time"}
+            if dt_pipe is not None:
+                out["pipelined"] = {"frames_in_flight": 2, "value": round(args.steps * W * H / dt_pipe / 1e6, 2),
+                                    "unit": "Mpixels/s", "ms_per_step": round(dt_pipe / args.steps * 1e3, 4),
+                                    "valu_frac": round(8.0 * executed / (dt_pipe / args.steps) / 1e12 / peak, 4),
+                                    "note": "informational: two render contexts on two streams, frames alternating; "
+                                            "the headline value above runs one frame at a time"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(w)
         else:
