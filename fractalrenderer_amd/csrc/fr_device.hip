@@ -178,7 +178,7 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "diag_stride")) {
         c->diag_stride = (size_t)value;               /* u64 words between the diag regions of consecutive stages */
     } else if (!strcmp(name, "queue_flags")) {
-        c->tune_queue_flags = (uint32_t)value;         /* 0 = automatic; else 0x100 | kQueueScatter | kQueuePrefetch */
+        c->tune_queue_flags = (uint32_t)value;         /* retired (bit-reversed order / claim-ahead): accepted, ignored */
     } else if (!strcmp(name, "probes")) {
         c->tune_probes = (uint32_t)value & 0xFu;
     } else if (!strcmp(name, "stream_probes")) {
@@ -367,10 +367,8 @@ static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t
     q.nsx_shift = -1;
     q.n_items = q.nsx * ((rows_local + 7) / 8);
     q.n_blk = (q.n_items + kShardBlock - 1) / kShardBlock;
-    uint32_t bits = ceil_log2(q.n_blk);
-    if (bits < 1) bits = 1;
-    q.n_blk_padded = 1u << bits;
-    q.blk_rev_shift = 32u - bits;
+    q.n_blk_padded = q.n_blk;
+    q.blk_rev_shift = 0;
     uint32_t grid = (uint32_t)c->compute_units * 8u;
     const uint32_t max_grid = (q.n_items + 3) / 4;
     if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
@@ -442,10 +440,8 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
     const uint32_t nsy = (rows_local + fph - 1) / fph;
     tq.n_items = tq.nsx * nsy;
     tq.n_blk = (tq.n_items + kShardBlock - 1) / kShardBlock;
-    uint32_t bits = ceil_log2(tq.n_blk);
-    if (bits < 1) bits = 1;
-    tq.n_blk_padded = 1u << bits;
-    tq.blk_rev_shift = 32u - bits;
+    tq.n_blk_padded = tq.n_blk;
+    tq.blk_rev_shift = 0;
 
     /* The fp64 tile kernel holds 5 workgroups of 256 threads per CU (the per-wave timeline of the diag buffer
      * shows workgroups beyond the resident set only start when resident ones exit, and find the queue dry):
@@ -473,8 +469,7 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
         tq.run_min = c->tune_run_min ? c->tune_run_min : 2u;
     }
     if (tq.run_min > tq.run_max) tq.run_min = tq.run_max;
-    /* no claim-ahead by default: measured equal or better without it on every workload */
-    tq.flags = c->tune_queue_flags ? (c->tune_queue_flags & 0x0Fu) : 0u;
+    tq.flags = 0u;
     /* Bounded items are dealt evenly to the shards, so a wave whose home shard is dry exits instead of
      * probing the other 7 (measured: the exit storm of 4096 waves x 8 serialized atomics costs 31 us of the
      * 260 us tile pass of C2 and 36 of the 74 us of a 1/8 shard, profiles/r01_probe_limit.txt).  Unbounded
@@ -688,7 +683,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         {
             uint32_t probes = c->tune_stream_probes ? c->tune_stream_probes : (rotate_regions ? 4u : 0u);
             if (sgrid < 64u) probes = 0;
-            a.q.flags = (tq.flags & kQueuePrefetch) | (probes << kQueueProbeShift);
+            a.q.flags = probes << kQueueProbeShift;
         }
         a.diag = c->diag ? c->diag + (size_t)k * c->diag_stride : nullptr;
         if (pool_stream) {
@@ -704,7 +699,6 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
              * a 315 us drain on C2; a block of 64 interior records is ~60 us of work at 5 waves/SIMD) */
             a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 1u;
             a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 2u;
-            a.q.flags &= ~kQueuePrefetch;
             if (k >= 2) {
                 /* follow-up passes read the partial blocks evicted by the previous pass (a few lanes per
                  * block): claim several per dequeue so that the records fill whole waves */

@@ -54,8 +54,6 @@ constexpr int kShards = 8;               /* one queue head per XCD              
 constexpr int kShardStrideWords = 32;    /* 128 B between heads                            */
 constexpr int kShardBlock = 16;          /* sub-tiles are dealt to shards in blocks of 16  */
 constexpr int kFastBlock = 16;           /* iterations per unchecked block                 */
-constexpr uint32_t kQueueScatter = 1u;   /* bit-reversed block order                       */
-constexpr uint32_t kQueuePrefetch = 2u;  /* issue the next dequeue before iterating the current run */
 constexpr uint32_t kQueueProbeShift = 4; /* bits 4-7: shards a wave may probe before giving up (0 = all 8) */
 constexpr uint32_t kInvalidPixel = 0xFFFFFFFFu;
 constexpr int kRingSlots = 128;          /* survivor ring capacity per wave (records)      */
@@ -78,11 +76,12 @@ struct QueueArgs {
     uint32_t nsx;                /* sub-tiles per sub-tile row                    */
     int32_t  nsx_shift;          /* log2(nsx) when nsx is a power of two, else -1 */
     uint32_t n_blk;              /* blocks of kShardBlock sub-tiles               */
-    uint32_t n_blk_padded;       /* n_blk rounded up to a power of two (index space the shards deal from) */
-    uint32_t blk_rev_shift;      /* 32 - log2(n_blk_padded): bit-reversal scatter of the block order */
+    uint32_t n_blk_padded;       /* = n_blk (kept for layout; a bit-reversed block order over a padded index
+                                  * space and claim-ahead were measured slower everywhere and removed) */
+    uint32_t blk_rev_shift;      /* unused */
     uint32_t run_shift;          /* run length = clamp(remaining >> run_shift, run_min, run_max) */
     uint32_t run_max, run_min;
-    uint32_t flags;              /* kQueueScatter | kQueuePrefetch */
+    uint32_t flags;              /* bits 4-7: probe limit (kQueueProbeShift) */
 };
 
 /* Kernel argument block (passed by value; lands in SGPRs / the scalar cache). */
@@ -387,9 +386,8 @@ __device__ __forceinline__ uint32_t xcc_id()
  * 8 heads, one per XCD.  A wave claims a run of items from its home shard with one atomicAdd,
  * run length clamp(remaining >> run_shift, run_min, run_max); when a shard is dry it moves to
  * the next one and returns false after `max_tries` shards (all 8 by default) were found dry -- every
- * wave reaches that.  With
- * kQueuePrefetch the next claim is issued when a run is handed out, so its latency hides under the
- * run's arithmetic (at the price of committing the wave to one more run). */
+ * wave reaches that.  (Claiming the next run ahead of need was measured equal or slower on every
+ * workload -- it commits the wave to one more run -- and is gone: the state it carried cost SGPRs.) */
 struct WaveQueue {
     uint32_t* heads;
     uint32_t n_groups, group;     /* groups dealt round-robin: shard k owns groups k, k+8, ... of `group` items */
@@ -398,8 +396,7 @@ struct WaveQueue {
     uint32_t run_shift, run_min, run_max;
     uint32_t lane;
     uint32_t shard, tried, seen, max_tries;
-    uint32_t cur_n, cur_raw, next_n, next_raw;
-    bool prefetch, started, pending;
+    uint32_t cur_n, cur_raw;
 
     __device__ __forceinline__ uint32_t shard_len(uint32_t sh) const
     {
@@ -424,19 +421,18 @@ struct WaveQueue {
         return v;
     }
     __device__ __forceinline__ void init(uint32_t* h, uint32_t groups, uint32_t group_items, uint32_t shift,
-                                         uint32_t rmin, uint32_t rmax, bool pf, uint32_t ln)
+                                         uint32_t rmin, uint32_t rmax, uint32_t ln)
     {
         heads = h;
         n_groups = groups; group = group_items; len_words = nullptr; len_cap = 0;
-        run_shift = shift; run_min = rmin; run_max = rmax; prefetch = pf; lane = ln;
+        run_shift = shift; run_min = rmin; run_max = rmax; lane = ln;
         shard = xcc_id(); tried = 0; seen = 0; max_tries = (uint32_t)kShards;
-        cur_n = cur_raw = next_n = next_raw = 0;
-        started = false; pending = false;
+        cur_n = cur_raw = 0;
     }
     __device__ __forceinline__ void init_lengths(uint32_t* h, const uint32_t* lengths, uint32_t cap, uint32_t shift,
-                                                 uint32_t rmin, uint32_t rmax, bool pf, uint32_t ln)
+                                                 uint32_t rmin, uint32_t rmax, uint32_t ln)
     {
-        init(h, 0, 1, shift, rmin, rmax, pf, ln);
+        init(h, 0, 1, shift, rmin, rmax, ln);
         len_words = lengths; len_cap = cap;
     }
     /* Probing every other shard before exiting costs up to 8 dependent atomics per wave, and all waves of
@@ -455,18 +451,13 @@ struct WaveQueue {
     /* hands out the next run [begin, begin+count) of shard `sh`; false = no work left anywhere */
     __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& count, uint32_t& sh)
     {
-        if (pending) { cur_n = next_n; cur_raw = next_raw; }
-        else {
-            /* shards known to be empty cost no atomic (a follow-up pass may have nothing to do) */
-            while (shard_len(shard) == 0u) {
-                if (++tried >= max_tries) return false;
-                shard = (shard + 1u) & (uint32_t)(kShards - 1);
-                seen = 0;
-            }
-            cur_n = run_len(shard, seen); cur_raw = claim(shard, cur_n);
+        /* shards known to be empty cost no atomic (a follow-up pass may have nothing to do) */
+        while (shard_len(shard) == 0u) {
+            if (++tried >= max_tries) return false;
+            shard = (shard + 1u) & (uint32_t)(kShards - 1);
+            seen = 0;
         }
-        pending = false;
-        started = true;
+        cur_n = run_len(shard, seen); cur_raw = claim(shard, cur_n);
         for (;;) {
             const uint32_t b = __builtin_amdgcn_readfirstlane(cur_raw);
             const uint32_t l = shard_len(shard);
@@ -484,7 +475,6 @@ struct WaveQueue {
             if (b + c > l) c = l - b;
             seen = b + c;
             begin = b; count = c; sh = shard;
-            if (prefetch) { next_n = run_len(shard, seen); next_raw = claim(shard, next_n); pending = true; }
             return true;
         }
     }
@@ -800,8 +790,7 @@ tile_kernel(const LaunchArgs A)
     writer.init(&rings[EFFECTS ? 0 : (threadIdx.x >> 6)], A.out, (uint32_t)lane);
 
     WaveQueue q;
-    q.init(A.q.heads, A.q.n_blk_padded, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max,
-           (A.q.flags & kQueuePrefetch) != 0, (uint32_t)lane);
+    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, (uint32_t)lane);
     q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
@@ -813,10 +802,8 @@ tile_kernel(const LaunchArgs A)
         ++diag_claims;
         diag_items += count;
         for (uint32_t j = begin; j < begin + count; ++j) {
-            /* shard-local index -> sub-tile id: blocks of kShardBlock sub-tiles dealt round-robin to
-             * the shards, optionally in bit-reversed (scattered) block order */
-            const uint32_t dealt = (j / kShardBlock) * kShards + cur_shard;
-            const uint32_t blk = (A.q.flags & kQueueScatter) ? __builtin_bitreverse32(dealt) >> A.q.blk_rev_shift : dealt;
+            /* shard-local index -> sub-tile id: blocks of kShardBlock sub-tiles dealt round-robin to the shards */
+            const uint32_t blk = (j / kShardBlock) * kShards + cur_shard;
             if (blk >= A.q.n_blk) continue;
             const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
             if (sid >= A.q.n_items) continue;
@@ -1042,8 +1029,7 @@ stream_kernel(const LaunchArgs A)
 
     /* region k of the input stream is shard k of the queue; its length was written by the previous launch */
     WaveQueue q;
-    q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max,
-                   (A.q.flags & kQueuePrefetch) != 0, lane);
+    q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
     q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
@@ -1189,11 +1175,9 @@ pool_kernel(const LaunchArgs A)
 
     WaveQueue q;
     if constexpr (FROM_STREAM)
-        q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max,
-                       (A.q.flags & kQueuePrefetch) != 0, lane);
+        q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
     else
-        q.init(A.q.heads, A.q.n_blk_padded, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max,
-               (A.q.flags & kQueuePrefetch) != 0, lane);
+        q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
     q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
@@ -1274,8 +1258,7 @@ pool_kernel(const LaunchArgs A)
                         }
                     } else {
                         /* pixel l of sub-tile j (shard-local index) */
-                        const uint32_t dealt = (j / kShardBlock) * kShards + res_shard;
-                        const uint32_t blk = (A.q.flags & kQueueScatter) ? __builtin_bitreverse32(dealt) >> A.q.blk_rev_shift : dealt;
+                        const uint32_t blk = (j / kShardBlock) * kShards + res_shard;
                         const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
                         const uint32_t sty = A.q.nsx_shift >= 0 ? sid >> A.q.nsx_shift : sid / A.q.nsx;
                         const uint32_t stx = sid - sty * A.q.nsx;
@@ -1516,7 +1499,7 @@ deep_zoom_kernel(const DeepZoomArgs A)
     const int n_ref = max_iter < ref_iter ? max_iter : ref_iter;
 
     WaveQueue q;
-    q.init(A.q.heads, A.q.n_blk_padded, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, false, lane);
+    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
     uint32_t begin, count, cur_shard;
     while (q.next(begin, count, cur_shard)) {
         for (uint32_t j = begin; j < begin + count; ++j) {

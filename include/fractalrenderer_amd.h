@@ -213,7 +213,8 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "stage_ratio"        budget growth per stream pass (default 4)
  *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue may claim in a stream pass
  *   "stream_workgroups_per_cu"          workgroups per compute unit of the stream pass
- *   "queue_flags"        0x100 | 1 (bit-reversed tile order) | 2 (prefetch the next dequeue)
+ *   "queue_flags"        retired: bit-reversed tile order and claim-ahead measured slower everywhere and were
+ *                        removed from the kernels; the option is accepted and ignored
  *   "probes", "stream_probes"  queue shards a wave tries before it exits, tile pass / stream passes
  *                        (1..8; 0 = automatic: 1 for a staged tile pass, 4 for its stream passes, 8 otherwise)
  *   "stream_rotate"      2 = survivor-stream writers rotate over the 8 regions (equal regions), 1 = one region
