@@ -515,13 +515,9 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, int bo
         if (nstage >= 2 && max_iter - bounds[nstage - 1] < bounds[nstage - 1] / 4) --nstage;
     }
     bounds[nstage++] = max_iter;
-    if (nstage > 1 && mode == 3) {
-        /* lane-pool passes all run to max_iter; each hands the lanes it would have to run out alone (queue
-         * dry, few lanes left per wave) to the next, much smaller pass; the last runs out.  Measured:
-         * follow-up passes cost more than they save, so the default is one */
-        const int extra = c->tune_pool_passes ? (int)c->tune_pool_passes - 1 : 0;
-        for (int k = 0; k < extra && nstage < kMaxStages; ++k) bounds[nstage++] = max_iter;
-    }
+    /* (follow-up lane-pool passes fed by lanes evicted from the first one -- "pool_passes" -- measured slower
+     * than letting every wave run its lanes out, and carrying the eviction path cost the pool kernel
+     * registers: removed; the option is accepted and ignored) */
     return nstage;
 }
 
@@ -691,19 +687,13 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
             a.i1 = max_iter;
             a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
             if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
-            a.pool_evict_at = c->tune_pool_evict ? c->tune_pool_evict : 32u;
-            if (k == nstage - 1) { a.out.base = nullptr; a.pool_evict_at = 0; }      /* last pass runs everything out */
+            a.out.base = nullptr;                                   /* the pool pass runs everything out */
             /* a lane-pool wave holds its claimed blocks as a private reserve and only stalls for a dequeue
              * once per reserve, so claim little and never ahead: what a wave has reserved when the queue
              * runs dry is exactly the tail of the pass (measured: 1-3 block runs + one run prefetched left
              * a 315 us drain on C2; a block of 64 interior records is ~60 us of work at 5 waves/SIMD) */
             a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 1u;
             a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 2u;
-            if (k >= 2) {
-                /* follow-up passes read the partial blocks evicted by the previous pass (a few lanes per
-                 * block): claim several per dequeue so that the records fill whole waves */
-                a.q.run_min = 4u; a.q.run_max = 8u;
-            }
             e = by_variant(fractal, f64, [&](auto t, auto f) {
                 return launch_stream_pool<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
         } else {

@@ -118,7 +118,7 @@ struct LaunchArgs {
     int32_t i0, i1;
     StreamRef in, out;
     uint32_t pool_refill_at;     /* lane pool: finished lanes wait until this many are idle */
-    uint32_t pool_evict_at;      /* lane pool over a stream: queue dry and <= this many lanes running -> hand them to `out` */
+    uint32_t pool_evict_at;      /* unused (eviction to follow-up pool passes measured slower and was removed) */
     /* outputs */
     float4* rgba;
     void* nu;
@@ -1147,7 +1147,6 @@ pool_kernel(const LaunchArgs A)
     constexpr size_t kBlockBytes = RingWriter<T, NF>::kBlockBytes;
 
     __shared__ LdsBlock S;
-    __shared__ WaveRing<T, NF> rings[FROM_STREAM ? kWavesPerBlock : 1];
     stage_constants(S, A);
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -1164,14 +1163,7 @@ pool_kernel(const LaunchArgs A)
     const bool want_nu = want_rgb || A.nu != nullptr;
     const bool fast_ok = A.fast_ok != 0;
     const uint32_t refill_at = A.pool_refill_at;
-    /* a wave left with at most this many running lanes once the queue is dry hands them to A.out
-     * (the next, much smaller pool pass packs such leftovers into full waves) instead of running
-     * them out alone */
-    const uint32_t evict_at = (FROM_STREAM && A.out.base) ? A.pool_evict_at : 0u;
     (void)inv_w; (void)aspect; (void)H; (void)W; (void)center_x; (void)center_y; (void)zoom; (void)resx; (void)resy; (void)inv_h;
-
-    RingWriter<T, NF> writer;
-    writer.init(&rings[FROM_STREAM ? (threadIdx.x >> 6) : 0], A.out, lane);
 
     WaveQueue q;
     if constexpr (FROM_STREAM)
@@ -1320,15 +1312,6 @@ pool_kernel(const LaunchArgs A)
         /* a wave that can no longer refill is on the critical path of the launch: give it issue priority */
         if (dry) __builtin_amdgcn_s_setprio(3);
         if constexpr (FROM_STREAM) {
-            if (dry && nactive <= evict_at) {
-                /* hand the last few running lanes to the next pass */
-                const T rec4[4] = {o.X, o.Yd, o.cx, o.cyd};
-                T rec[NF];
-                for (int k = 0; k < NF; ++k) rec[k] = rec4[k];
-                writer.append(pixel != kInvalidPixel, pixel, (uint32_t)max_iter - (deadline - wclock), rec);
-                writer.finish();
-                break;
-            }
             /* records carry their own progress, so deadlines are not monotone: keep the true minimum */
             next_deadline = wclock + wave_min_u32<T>(pixel != kInvalidPixel ? deadline - wclock : 0xFFFFFFFFu);
             have_running = true;

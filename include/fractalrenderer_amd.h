@@ -204,8 +204,8 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "shift_bias"         signed change of log2 of the guided-run divisor
  *   "pool"               2 = lane-pool kernel (lanes are refilled with the next pixel as they finish),
  *                        1 = off, 0 = automatic;  "pool_refill_at" = idle lanes that trigger a refill;
- *                        "pool_passes" = lane-pool passes over the survivors (staging 3), "pool_evict_at" =
- *                        running lanes at or below which a wave hands its leftovers to the next pass
+ *                        "pool_passes", "pool_evict_at": retired (follow-up passes fed by evicted lanes measured
+ *                        slower and were removed); accepted and ignored
  *   "staging"            3 = tile pass for the first "stage_first" iterations + ONE lane-pool pass over the
  *                        compacted survivors to max_iter, 2 = tile pass + block stream passes, 1 = single pass,
  *                        0 = automatic (= 3 wherever it applies: no SSAA, no trap/stripe effects)
