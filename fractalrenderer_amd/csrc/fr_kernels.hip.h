@@ -769,9 +769,11 @@ tile_kernel(const LaunchArgs A)
 
     /* viewport constants out of LDS (broadcast reads), narrowed as the reference narrows
      * them for its fp32 shaders (src/compute_effect_manager.h:85-90) */
-    const int W = S.W, H = S.H, max_iter = S.max_iter;
+    /* integers straight from the kernel arguments (wave-uniform SGPRs); through LDS they would be VGPR values
+     * and everything derived from them would count as divergent */
+    const int W = A.W, H = A.H, max_iter = A.max_iter;
     /* SSAA = false: the one-sample variant (the sample loop and its state fold away: fewer live SGPRs) */
-    const int aa = SSAA ? (S.aa > 1 ? S.aa : 1) : 1;
+    const int aa = SSAA ? (A.aa > 1 ? A.aa : 1) : 1;
     const T center_x = (T)S.center_x, center_y = (T)S.center_y, zoom = (T)S.zoom;
     const T bailout = (T)S.bailout;
     const T B2 = bailout * bailout;
@@ -1017,7 +1019,7 @@ stream_kernel(const LaunchArgs A)
     stage_constants(S, A);
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const int max_iter = S.max_iter;
+    const int max_iter = A.max_iter;
     const T bailout = (T)S.bailout;
     const T B2 = bailout * bailout;
     const bool want_rgb = A.rgba != nullptr;
@@ -1150,7 +1152,9 @@ pool_kernel(const LaunchArgs A)
     stage_constants(S, A);
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const int W = S.W, H = S.H, max_iter = S.max_iter;
+    /* integers straight from the kernel arguments (wave-uniform SGPRs); through LDS they would be VGPR values
+     * and everything derived from them would count as divergent */
+    const int W = A.W, H = A.H, max_iter = A.max_iter;
     const T center_x = (T)S.center_x, center_y = (T)S.center_y, zoom = (T)S.zoom;
     const T bailout = (T)S.bailout;
     const T B2 = bailout * bailout;
