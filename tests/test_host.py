@@ -526,3 +526,21 @@ def test_hot_kernels_keep_their_register_budget(fr):
         assert u, "kernel %s not found in the resource remarks" % name
         assert u["ScratchSize [bytes/lane]"] == 0, (name, u)
         assert u["VGPRs"] <= max_vgpr and u["Occupancy [waves/SIMD]"] >= min_occ and u["SGPRs Spill"] <= max_spill, (name, u)
+
+
+def test_host_code_under_address_and_ub_sanitizers(golden, tmp_path):
+    """The C host side (fr_host.c, fr_franim.c, fr_frameio.c) built with -fsanitize=address,undefined (CPU build
+    only: GPU sanitizers are not available on the pool) and driven by tests/c_client/fuzz_host.c: truncated and
+    corrupted .franim inputs, interpolation outside the keyframe range, save / re-parse, multi-band PNG writes."""
+    import subprocess
+    csrc = os.path.join(ROOT, "fractalrenderer_amd", "csrc")
+    exe = str(tmp_path / "fuzz_host")
+    cmd = ["gcc", "-std=c11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+           os.path.join(csrc, "fr_host.c"), os.path.join(csrc, "fr_franim.c"), os.path.join(csrc, "fr_frameio.c"),
+           os.path.join(ROOT, "tests", "c_client", "fuzz_host.c"), "-o", exe, "-lm", "-lz", "-lpthread"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    run = subprocess.run([exe, golden["franim"], str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "ERROR" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+    assert run.stdout.startswith("parsed ok")
