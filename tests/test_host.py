@@ -528,19 +528,24 @@ def test_hot_kernels_keep_their_register_budget(fr):
         assert u["VGPRs"] <= max_vgpr and u["Occupancy [waves/SIMD]"] >= min_occ and u["SGPRs Spill"] <= max_spill, (name, u)
 
 
-def test_host_code_under_address_and_ub_sanitizers(golden, tmp_path):
-    """The C host side (fr_host.c, fr_franim.c, fr_frameio.c) built with -fsanitize=address,undefined (CPU build
-    only: GPU sanitizers are not available on the pool) and driven by tests/c_client/fuzz_host.c: truncated and
-    corrupted .franim inputs, interpolation outside the keyframe range, save / re-parse, multi-band PNG writes."""
+def test_host_code_under_sanitizers(golden, tmp_path, monkeypatch):
+    """The C host side (fr_host.c, fr_franim.c, fr_frameio.c) built with -fsanitize=address,undefined and with
+    -fsanitize=thread (CPU builds only: GPU sanitizers are not available on the pool) and driven by
+    tests/c_client/fuzz_host.c: truncated and corrupted .franim inputs, interpolation outside the keyframe range,
+    save / re-parse, multi-band PNG writes on 8 worker threads."""
     import subprocess
     csrc = os.path.join(ROOT, "fractalrenderer_amd", "csrc")
-    exe = str(tmp_path / "fuzz_host")
-    cmd = ["gcc", "-std=c11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-           "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
-           os.path.join(csrc, "fr_host.c"), os.path.join(csrc, "fr_franim.c"), os.path.join(csrc, "fr_frameio.c"),
-           os.path.join(ROOT, "tests", "c_client", "fuzz_host.c"), "-o", exe, "-lm", "-lz", "-lpthread"]
-    out = subprocess.run(cmd, capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr[-2000:]
-    run = subprocess.run([exe, golden["franim"], str(tmp_path)], capture_output=True, text=True, timeout=300)
-    assert run.returncode == 0 and "ERROR" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
-    assert run.stdout.startswith("parsed ok")
+    monkeypatch.setenv("FR_PNG_THREADS", "8")
+    for tag, flags in (("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]),
+                       ("tsan", ["-fsanitize=thread"])):
+        exe = str(tmp_path / ("fuzz_host_" + tag))
+        cmd = ["gcc", "-std=c11", "-g", "-O1", *flags, "-fno-omit-frame-pointer",
+               "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+               os.path.join(csrc, "fr_host.c"), os.path.join(csrc, "fr_franim.c"), os.path.join(csrc, "fr_frameio.c"),
+               os.path.join(ROOT, "tests", "c_client", "fuzz_host.c"), "-o", exe, "-lm", "-lz", "-lpthread"]
+        out = subprocess.run(cmd, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        run = subprocess.run([exe, golden["franim"], str(tmp_path)], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0 and "ERROR" not in run.stderr and "WARNING: ThreadSanitizer" not in run.stderr \
+            and "runtime error" not in run.stderr, (tag, run.stderr[-3000:])
+        assert run.stdout.startswith("parsed ok")
