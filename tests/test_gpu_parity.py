@@ -803,3 +803,46 @@ def test_plain_c_client_renders_through_the_abi(fr, tmp_path):
     exe = build_c_client(tmp_path)
     out = subprocess.run([exe, "gpu", str(tmp_path / "g.png")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "gpu ok", out.stderr
+
+
+def test_distinct_contexts_render_concurrently_from_host_threads(fr):
+    """The header's threading contract: one fr_ctx is not re-entrant, distinct contexts may run concurrently.
+    Four host threads, a context each (ctypes releases the GIL inside the calls), different views; every
+    frame must be bit-identical to the same view rendered alone."""
+    import threading
+    import torch
+    W, H = 384, 256
+    views = [fr.FractalState(max_iterations=300 + 50 * k, center_x=-0.6 + 0.05 * k, zoom=2.5 - 0.3 * k) for k in range(4)]
+    solo = []
+    r0 = fr.Renderer(0)
+    for st in views:
+        nu = torch.empty((H, W), dtype=torch.float64, device="cuda:0")
+        r0.render(st, W, H, nu=nu)
+        solo.append(nu.clone())
+    r0.close()
+    results = [[] for _ in views]
+    errors = []
+
+    def worker(k):
+        try:
+            r = fr.Renderer(0)
+            for _ in range(12):
+                nu = torch.empty((H, W), dtype=torch.float64, device="cuda:0")
+                rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+                r.render(views[k], W, H, nu=nu, rgba=rgba)
+                results[k].append(bool(torch.equal(nu, solo[k])))
+            # an error in one thread must not leak into another thread's last-error string
+            with pytest.raises(fr.FractalRendererError) as e:
+                r.render(fr.FractalState(max_iterations=-k - 1), W, H, nu=nu)
+            assert str(-k - 1) in str(e.value)
+            r.close()
+        except Exception as ex:      # noqa: BLE001
+            errors.append((k, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(views))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    assert all(len(r) == 12 and all(r) for r in results), results
