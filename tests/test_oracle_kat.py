@@ -290,3 +290,65 @@ def test_workload_statistics_match_survey(oracle):
     assert abs(f.executed / 256 ** 2 - 48.5) < 1.0 and abs((f.iter == 256).mean() - 0.169) < 0.01
     f = oracle.render(oracle.OracleParams(max_iterations=1024), 256, 256)
     assert abs(f.executed / 256 ** 2 - 177.9) < 2.0
+
+
+# ---- constants pinned by the reference's compiled shaders ---------------------------------------------
+def _float_literals(text):
+    import re
+    import struct
+    vals = set()
+    for m in re.finditer(r"(?<![\w.])(\d+\.\d*(?:[eE][-+]?\d+)?|\.\d+)f\b", text):
+        vals.add(struct.unpack("<I", struct.pack("<f", float(m.group(1))))[0])
+    return vals
+
+
+def _function_body(src, signature):
+    i = src.rindex(signature)            # the definition, not a forward declaration
+    j = src.index("{", i)
+    depth, k = 0, j
+    while True:
+        depth += {"{": 1, "}": -1}.get(src[k], 0)
+        if depth == 0:
+            return src[j:k + 1]
+        k += 1
+
+
+def test_palette_and_post_chain_literals_exist_in_the_reference_spirv():
+    """tests/golden/spv_constants.json holds the float constants of the reference's compiled shaders
+    (shaders/*.comp.spv; extracted by tests/golden/make_spv_constants.py).  Every float literal typed into the
+    palette and post-chain code of the oracle AND of the library's knot-table builder must be one of them:
+    a mistyped knot, break point, exponent or tonemap coefficient would not be."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spv = json.load(open(os.path.join(root, "tests", "golden", "spv_constants.json")))
+    sets = {k: set(v["float32_bits"]) for k, v in spv.items()}
+    oracle_c = open(os.path.join(root, "oracle", "fr_oracle.c")).read()
+    host_c = open(os.path.join(root, "fractalrenderer_amd", "csrc", "fr_host.c")).read()
+    # (smoothstep is a GLSL built-in, an extended instruction in SPIR-V: its 3 - 2t polynomial has no constants there)
+    shared = _float_literals(_function_body(oracle_c, "static void ramp_quarters(")) | \
+        _float_literals(_function_body(oracle_c, "static void ramp_fifths("))
+    checks = [
+        ("mandelbrot", _float_literals(_function_body(oracle_c, "static void palette_mandelbrot(")) | shared),
+        ("julia", _float_literals(_function_body(oracle_c, "static void palette_julia(")) | shared),
+        ("burning_ship", _float_literals(_function_body(oracle_c, "static void palette_julia(")) | shared),
+        ("mandelbrot", _float_literals(_function_body(oracle_c, "static inline float aces("))),
+        ("julia", _float_literals(_function_body(oracle_c, "static inline float aces("))),
+        # enhance_color + gamma: the shader's 1.0 / 2.2 is folded to one constant in the binary (checked below)
+        ("mandelbrot", _float_literals(_function_body(oracle_c, "void fro_post_chain(")) - _float_literals("2.2f")),
+    ]
+    # the library's own table builder (both shaders' numbering in one function)
+    table = _float_literals(_function_body(host_c, "static void palette_table_fill(")) | \
+        _float_literals(_function_body(host_c, "static void ramp_quarters(")) | \
+        _float_literals(_function_body(host_c, "static void ramp_fifths("))
+    assert len(table) > 20
+    assert table <= (sets["mandelbrot"] | sets["julia"]), sorted(table - (sets["mandelbrot"] | sets["julia"]))
+    for shader, lits in checks:
+        assert lits, shader
+        missing = lits - sets[shader]
+        assert not missing, (shader, [__import__("struct").unpack("<f", __import__("struct").pack("<I", b))[0] for b in sorted(missing)])
+    # folded constants the GLSL compiler left behind: log(2.0) and 1.0/2.2 as float32
+    import struct
+    f32 = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]  # noqa: E731
+    assert f32(0.6931471805599453) in sets["mandelbrot"] and f32(1.0 / 2.2) in sets["mandelbrot"]
+    assert f32(1e20) in sets["mandelbrot"] and f32(1e10) in sets["burning_ship"]      # min_trap / min_orbit_dist seeds
