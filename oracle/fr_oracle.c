@@ -1,8 +1,9 @@
 /*
  * fr_oracle.c -- CPU restatement of the reference's escape-time hot path.
  *
- * TEST INFRASTRUCTURE ONLY; see fr_oracle.h.  PARITY UNPINNED BY THE REFERENCE
- * (it holds no tests or golden vectors and its implementation is GLSL/Vulkan).
+ * TEST INFRASTRUCTURE ONLY; see fr_oracle.h.  Parity pin: the reference holds no tests or
+ * golden vectors; the fp32 variants are checked against vectors obtained by executing the
+ * reference's compiled shaders (tests/golden/spv_frames.npz, tests/test_spv_golden.py).
  *
  * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp).
  */

@@ -5,14 +5,26 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library, and only as the checker / the timed CPU baseline.
  *
- * PARITY UNPINNED BY THE REFERENCE: franklynch/FractalRenderer ships no
- * tests, golden images or known-answer vectors for this path, and its only
- * implementation of it is GLSL/Vulkan (fp32), which cannot be compiled or
- * run in this image.  The restatement is therefore pinned by
+ * PARITY PIN: franklynch/FractalRenderer ships no tests, golden images or
+ * known-answer vectors for this path, and its only implementation of it is
+ * GLSL/Vulkan (fp32), which no driver in this image can run.  It does ship its
+ * shaders COMPILED (shaders/<name>.comp.spv), so the fp32 variants are pinned against
+ * OUTPUTS OF THOSE BINARIES: tests/golden/make_spv_golden.py executes them,
+ * one invocation per pixel, through the SPIR-V interpreter
+ * tests/golden/spirv_interp.py (ours; IEEE binary32, one rounding per
+ * instruction) and commits what they write as tests/golden/spv_frames.npz
+ * (56 cases over mandelbrot / julia / burning_ship / test_deep_zoom);
+ * tests/test_spv_golden.py requires this restatement to reproduce them --
+ * escape indices bit-exact, written texels within 5e-6.  The fp64 variants
+ * have no counterpart in the reference (it has no fp64 shader): they are the
+ * same source compiled with REAL=double and are additionally pinned by
  *   (i)  analytic known answers (tests/test_oracle_kat.py),
  *   (ii) an independent numpy restatement (oracle/np_restatement.py) and an
  *        mpmath high-precision check of nu, and
  *   (iii) the reference's own data artefact FR/.franim for the animation rows.
+ * What is NOT claimed: that a Vulkan driver's code generation (fma
+ * contraction, fast transcendental approximations) yields the same bits as
+ * the interpreter; that latitude is what the colour tolerances are for.
  *
  * Path shorthand: shaders/ = /root/reference/FractalRenderer/shaders/,
  *                 src/     = /root/reference/FractalRenderer/src/.

@@ -1,6 +1,6 @@
 """Independent numpy restatement of the escape-time math, used ONLY to pin the C oracle.
 
-TEST INFRASTRUCTURE ONLY (see oracle/fr_oracle.h).  PARITY UNPINNED BY THE REFERENCE.
+TEST INFRASTRUCTURE ONLY (see oracle/fr_oracle.h, which states what pins the oracle to the reference).
 Written separately from fr_oracle.c (vectorised, masked updates instead of a scalar
 loop with break) so that an error in one restatement is unlikely to be repeated in the
 other.  Follows shaders/mandelbrot.comp:147-177, shaders/julia.comp:216-249,325 and

@@ -2,9 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg, never from the product package.
-PARITY UNPINNED BY THE REFERENCE (no tests/golden vectors exist upstream; the
-reference's GLSL/Vulkan implementation cannot run in this image) -- see
-fr_oracle.h for what pins the restatement instead.
+PARITY PIN: no tests or golden vectors exist upstream and no Vulkan driver runs in
+this image; the fp32 variants are pinned against vectors obtained by executing the
+reference's compiled shaders (tests/golden/spv_frames.npz) -- see fr_oracle.h.
 """
 from __future__ import annotations
 

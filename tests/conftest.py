@@ -47,3 +47,10 @@ def golden():
     return {"frames": np.load(os.path.join(g, "frames.npz")),
             "palettes": np.load(os.path.join(g, "palettes.npz")),
             "franim": os.path.join(g, "reference_sample.franim")}
+
+
+@pytest.fixture(scope="session")
+def spv_golden():
+    """Vectors produced by executing the reference's compiled shaders (tests/golden/make_spv_golden.py)."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "spv_frames.npz"))

@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from cases import CASES, MANDEL_PALETTES, JULIA_PALETTES, needs_effects
+from spv_cases import SPV_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -90,6 +91,18 @@ def test_case_matches_oracle_and_golden(fr, renderer, oracle, golden, name, shap
     check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
     g = golden["frames"]
     check_against(p, g[name + "/iter"], g[name + "/nu"], g[name + "/rgba"], rgba, nu, it)
+
+
+@pytest.mark.parametrize("name", sorted(SPV_CASES))
+def test_case_matches_the_executed_reference_shader(fr, renderer, oracle, spv_golden, name):
+    """The HIP path (fp32 variants, the arithmetic of the reference's shaders) against what the reference's compiled
+    SPIR-V wrote when executed by tests/golden/spirv_interp.py: escape indices bit-exact, texels within the colour bar
+    of check_against.  The oracle only supplies the planes the fixture lacks (nu for the wrap exception; SSAA cases)."""
+    shader, p, W, H = SPV_CASES[name]
+    rgba, nu, it = gpu_render(fr, renderer, p, W, H)
+    ref = oracle.render(p, W, H)
+    want_iter = spv_golden[name + "/iter"] if p.aa == 1 else ref.iter
+    check_against(p, want_iter, ref.nu, spv_golden[name + "/rgba"], rgba, nu, it)
 
 
 @pytest.mark.parametrize("max_iter", [1, 2, 5, 15, 16, 17, 31, 32, 33, 100])

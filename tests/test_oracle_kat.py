@@ -2,8 +2,8 @@
 high-precision (mpmath) check of nu, and the committed golden fixtures.
 
 The reference holds no tests or golden vectors for this path, so
-these known answers are the build's own; they are what "parity unpinned by the reference"
-is replaced with.  CPU only.
+these known answers are the build's own; the vectors that come from the reference's own
+artefact (its compiled shaders, executed) are checked in tests/test_spv_golden.py.  CPU only.
 """
 import math
 
