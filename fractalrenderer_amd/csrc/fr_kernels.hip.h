@@ -604,6 +604,32 @@ __device__ __forceinline__ void orbit_step(Orbit<T>& o)
     o.y2d = o.Yd * o.Yd;
 }
 
+/* fp32: gfx950 has packed two-wide fp32 multiplies and fmas (v_pk_mul_f32, v_pk_fma_f32).  Each half is an
+ * ordinary IEEE operation with its own rounding, so pairing operations of ONE pixel changes no bit:
+ * {X', Yd'} = {fma(1, t, cx), fma(2, p, cyd)}  (fma(1, t, cx) is RN(t + cx)) and {x2', y2d'} = {X', Yd'}^2:
+ * four VALU instructions per update instead of six.  The packed forms issue at half the rate of the scalar-width
+ * ones (profiles/r01_ubench_valu_rates.txt: 74.7 T values/s either way), so this is not a 1.5x: what it buys is
+ * issue slots and a shorter dependent chain -- measured +5.8 % on a 3840x2160 fp32 frame, +1.3 % on C3
+ * (profiles/r01_packed_fp32_step.txt). */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool ABS>
+__device__ __forceinline__ void orbit_step_f32(Orbit<float>& o)
+{
+    /* p through an asm statement: left to itself the vectoriser pairs this product with the squares
+     * (a second v_pk_mul_f32 with half its result unused) and then needs a v_mov to put p next to t */
+    const float t = __builtin_fmaf(-0.25f, o.y2d, o.x2);
+    float p;            /* t as a (textually unused) input orders the product after the fmac, so it can take y2d's register */
+    if (ABS) asm("v_mul_f32_e64 %0, |%1|, |%2|" : "=v"(p) : "v"(o.X), "v"(o.Yd), "v"(t));
+    else asm("v_mul_f32_e32 %0, %1, %2" : "=v"(p) : "v"(o.X), "v"(o.Yd), "v"(t));
+    const f32x2 tp = {t, p}, c = {o.cx, o.cyd}, k = {1.0f, 2.0f};
+    const f32x2 z = __builtin_elementwise_fma(k, tp, c);
+    const f32x2 sq = z * z;
+    o.X = z.x; o.Yd = z.y;
+    o.x2 = sq.x; o.y2d = sq.y;
+}
+template <> __device__ __forceinline__ void orbit_step<float, false>(Orbit<float>& o) { orbit_step_f32<false>(o); }
+template <> __device__ __forceinline__ void orbit_step<float, true>(Orbit<float>& o) { orbit_step_f32<true>(o); }
+
 /* 4 |z|^2 = RN(4 x2 + y2d): the escape test compares it with 4 B^2.  Scaling by a power of two commutes
  * with rounding, so this is exactly 4 * RN(zx^2 + zy^2) and the test is the as-written one; written this
  * way the multiplier 4.0 is an inline constant of a three-operand v_fma_f64 (0.25 is not: the compiler
