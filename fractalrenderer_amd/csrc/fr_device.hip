@@ -38,7 +38,8 @@ struct fr_ctx {
     size_t stream_bytes[2];
     uint32_t tune_pool;         /* 0 = automatic (currently off), 1 = off, 2 = on: lane-pool kernel */
     uint32_t tune_pool_refill;  /* idle lanes that trigger a refill (0 = 32) */
-    uint32_t tune_pool_evict;   /* stream pool: running lanes at or below which a dry wave evicts (0 = 32) */
+    uint32_t tune_pool_evict;   /* retired option, ignored */
+    uint32_t tune_periodicity;  /* 0 off; else the lane pool closes orbits that return to their own snapshot (window in iterations) */
     uint32_t tune_pool_passes;  /* stream pool passes (0 = 1) */
     uint32_t tune_staging;      /* 0 = automatic (currently off), 1 = off (single pass), 2 = on */
     uint32_t tune_stage_first;  /* first budget b0 (0 = 32) */
@@ -154,6 +155,9 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "pool_evict_at")) {
         if (value < 0 || value > 64) return fr_set_error(FR_ERR_INVALID_ARG, "pool_evict_at must be in [0,64]");
         c->tune_pool_evict = (uint32_t)value;
+    } else if (!strcmp(name, "periodicity")) {
+        if (value < 0 || value > (1 << 20)) return fr_set_error(FR_ERR_INVALID_ARG, "periodicity must be 0 (off), 1 (on) or a snapshot window in iterations");
+        c->tune_periodicity = value == 1 ? 128u : (uint32_t)((value + 15) / 16 * 16);
     } else if (!strcmp(name, "pool_passes")) {
         if (value < 0 || value > 8) return fr_set_error(FR_ERR_INVALID_ARG, "pool_passes must be in [0,8]");
         c->tune_pool_passes = (uint32_t)value;
@@ -282,7 +286,10 @@ static hipError_t launch_pool(int shape, dim3 grid, hipStream_t s, const LaunchA
 template <typename T, int FRACTAL>
 static hipError_t launch_stream_pool(dim3 grid, hipStream_t s, const LaunchArgs& a)
 {
-    hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, true>), grid, dim3(kBlockThreads), 0, s, a);
+    if (a.period_window)
+        hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, true, true>), grid, dim3(kBlockThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, true, false>), grid, dim3(kBlockThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -688,6 +695,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
             a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
             if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
             a.out.base = nullptr;                                   /* the pool pass runs everything out */
+            a.period_window = c->tune_periodicity;
             /* a lane-pool wave holds its claimed blocks as a private reserve and only stalls for a dequeue
              * once per reserve, so claim little and never ahead: what a wave has reserved when the queue
              * runs dry is exactly the tail of the pass (measured: 1-3 block runs + one run prefetched left

@@ -118,7 +118,7 @@ struct LaunchArgs {
     int32_t i0, i1;
     StreamRef in, out;
     uint32_t pool_refill_at;     /* lane pool: finished lanes wait until this many are idle */
-    uint32_t pool_evict_at;      /* unused (eviction to follow-up pool passes measured slower and was removed) */
+    uint32_t period_window;      /* lane pool, PERIOD variant: iterations between the snapshots cycles are looked for against */
     /* outputs */
     float4* rgba;
     void* nu;
@@ -1165,7 +1165,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 /* FROM_STREAM = false: lanes are refilled with fresh pixels (coordinates from the pixel index);
  * FROM_STREAM = true : lanes are refilled with survivor records of the tile pass (A.in), and run the
  *                      remaining iterations [A.i0, max_iter). */
-template <typename T, int FRACTAL, int FPW_LOG2, bool FROM_STREAM>
+template <typename T, int FRACTAL, int FPW_LOG2, bool FROM_STREAM, bool PERIOD = false>
 __global__ void __launch_bounds__(kBlockThreads)
 pool_kernel(const LaunchArgs A)
 {
@@ -1216,6 +1216,12 @@ pool_kernel(const LaunchArgs A)
     uint32_t deadline = 0;
     int esc_i = 0;
     T esc_r2 = T(0);
+    /* PERIOD: the lane's own state at the last snapshot (NaN: none since its refill) and "it came back to it" */
+    T refX = __builtin_nan(""), refYd = __builtin_nan("");
+    uint32_t cyc = 0;
+    uint32_t next_snap = 0;              /* wave-uniform: clock of the next snapshot */
+    uint32_t snap_window = A.period_window, snap_closed = 1u;   /* current window; lanes closed since the last snapshot */
+    const uint32_t snap_cap = A.period_window > (((uint32_t)A.max_iter >> 7) << 4) ? A.period_window : (((uint32_t)A.max_iter >> 7) << 4);
     /* wave-uniform state */
     uint32_t wclock = 0;
     uint32_t next_deadline = 0;          /* a lower bound of the earliest deadline among running lanes */
@@ -1277,6 +1283,7 @@ pool_kernel(const LaunchArgs A)
                             o.x2 = o.X * o.X;
                             o.y2d = o.Yd * o.Yd;
                             deadline = wclock + ((uint32_t)max_iter - done);
+                            if constexpr (PERIOD) { refX = __builtin_nan(""); refYd = refX; cyc = 0u; }
                         }
                     } else {
                         /* pixel l of sub-tile j (shard-local index) */
@@ -1295,6 +1302,7 @@ pool_kernel(const LaunchArgs A)
                             }
                             pixel = (uint32_t)lrow * (uint32_t)W + (uint32_t)px;
                             deadline = wclock + (uint32_t)max_iter;
+                            if constexpr (PERIOD) { refX = __builtin_nan(""); refYd = refX; cyc = 0u; }
                             if constexpr (FRACTAL == 0) {
                                 T uvx, uvy;                       /* shaders/mandelbrot.comp:149-151 */
                                 if (A.exact_div_ok) {
@@ -1367,6 +1375,33 @@ pool_kernel(const LaunchArgs A)
             have_running = rel != 0xFFFFFFFFu;
             next_deadline = wclock + (have_running ? rel : (uint32_t)max_iter);
         };
+        /* PERIOD.  A running lane whose state equals -- as numbers -- its own state at the last snapshot is on a
+         * cycle: the update is a deterministic function of (z, c), so it repeats for ever and the lane can never
+         * escape.  It is interior with exactly the result the remaining iterations would give (index max_iter;
+         * the plain colourings do not look at the final z).  Called where every running lane is known not to
+         * have escaped; also takes the next snapshot when its time has come. */
+        auto close_cycles = [&]() {
+            const bool running = pixel != kInvalidPixel && fin == 0u;
+            const bool hit = running && cyc != 0u;
+            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+                if (hit) {
+                    esc_i = max_iter; esc_r2 = T(0); fin = 1u; cyc = 0u;
+                    o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                }
+                const uint32_t nhit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+                newly += nhit;
+                snap_closed += nhit;
+            }
+            if ((int32_t)(wclock - next_snap) >= 0) {
+                refX = o.X; refYd = o.Yd;          /* parked lanes hold 0 == 0: masked by `running` above */
+                /* a cycle of period p shows at offsets that are multiples of lcm(16, p): a window that closed
+                 * nothing is doubled (up to max_iter / 8), so deep views with long periods are reached without
+                 * making the short cycles of shallow views wait */
+                if (snap_closed == 0u && snap_window < snap_cap) snap_window <<= 1;
+                snap_closed = 0u;
+                next_snap = wclock + snap_window;
+            }
+        };
         uint32_t clean = 0;            /* tested updates since the last escape */
         uint32_t streak = 0;           /* clean unchecked blocks in a row */
         while (newly < goal) {
@@ -1375,17 +1410,21 @@ pool_kernel(const LaunchArgs A)
                 /* after 2 (6) clean stretches in a row the wave runs 2 (4) blocks per snapshot / test (a half, a
                  * quarter of that overhead on the long interior runs that dominate deep views); a dirty one resets it */
                 const uint32_t reps = streak >= 6u ? 4u : (streak >= 2u ? 2u : 1u);
+                uint32_t seen = 0u;
                 for (uint32_t rep = 0; rep < reps; ++rep) {
 #pragma unroll
                     for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
+                    if constexpr (PERIOD) seen |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
                 }
                 if (__builtin_amdgcn_ballot_w64(!(orbit_r2x4(o) <= B2x4)) == 0ull) {
                     wclock += reps * (uint32_t)kFastBlock;
                     ++streak;
                     /* clean block: lanes at or past their deadline never escaped -> interior */
                     if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
+                    if constexpr (PERIOD) { cyc |= seen; close_cycles(); }
                     continue;
                 }
+                /* dirty: `seen` is dropped with the block (a lane that escaped inside it is not on a cycle) */
                 o.X = sX; o.Yd = sYd; o.x2 = sx2; o.y2d = sy2d;      /* roll back, replay tested */
                 fast = false;
                 streak = 0;
@@ -1420,6 +1459,11 @@ pool_kernel(const LaunchArgs A)
             wclock += k;
             clean = escaped ? 0u : clean + k;
             if (wclock == next_deadline) reach_deadline(false);
+            if constexpr (PERIOD) {
+                /* escaped lanes are parked and finished: only running lanes count, and those were tested every update */
+                cyc |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
+                close_cycles();
+            }
             /* back to unchecked blocks after a block's worth of updates without an escape */
             if (clean >= (uint32_t)kFastBlock) { fast = fast_ok; clean = 0; }
         }

@@ -219,6 +219,14 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                        (1..8; 0 = automatic: 1 for a staged tile pass, 4 for its stream passes, 8 otherwise)
  *   "stream_rotate"      2 = survivor-stream writers rotate over the 8 regions (equal regions), 1 = one region
  *                        per XCD, 0 = automatic (= 2)
+ *   "periodicity"        0 = off (default), 1 = on, N > 1 = on with a first snapshot window of N iterations.
+ *                        The lane-pool pass keeps, per lane, the orbit state at the last snapshot; a lane whose
+ *                        state returns to it is on a cycle, can never escape, and is retired as interior at once
+ *                        instead of being iterated to max_iter.  Exact, not a heuristic: the update is a
+ *                        deterministic function of (z, c), so every plane stays byte-identical
+ *                        (tests/test_gpu_parity.py::test_periodicity_never_changes_a_pixel).  No reference
+ *                        counterpart: the shaders iterate every interior sample to max_iter.  Off by default so
+ *                        that the default path executes exactly the reference's iteration count.
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1
  *   "diag_buffer"        device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks,
  *                        items processed, dequeues); 0 disables.  "diag_stride" = uint64 words

@@ -175,6 +175,88 @@ def test_all_palettes(fr, renderer, oracle):
             check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
 
 
+# ---- cycle closing in the lane pool ("periodicity") -------------------------------------------------------------
+@pytest.mark.parametrize("window", [1, 16, 48, 4096])
+@pytest.mark.parametrize("name", sorted(n for n, (p, _, _) in CASES.items()
+                                        if p.fractal in (0, 1, 2) and p.aa == 1 and not needs_effects(p) and p.max_iterations >= 128))
+def test_periodicity_never_changes_a_pixel(fr, renderer, oracle, name, window):
+    """An orbit that returns to its own earlier state can never escape: the lane pool may call it interior
+    at once.  Every plane must stay byte-identical to the run without the option, and match the oracle."""
+    p, W, H = CASES[name]
+    base = gpu_render(fr, renderer, p, W, H)
+    try:
+        renderer.set_option("periodicity", window)
+        cur = gpu_render(fr, renderer, p, W, H)
+    finally:
+        renderer.set_option("periodicity", 0)
+    for a, b in zip(base, cur):
+        assert np.array_equal(a, b)
+    ref = oracle.render(p, W, H)
+    check_against(p, ref.iter, ref.nu, ref.rgba, *cur)
+
+
+def test_periodicity_on_interior_heavy_views(fr, renderer, oracle):
+    """Views that are mostly interior (period 1, 2, 3 components, a period-39 minibrot neighbourhood), shards,
+    small refill thresholds: identical planes, and the pass gets shorter where cycles exist."""
+    import torch
+    views = [dict(center_x=-0.2, center_y=0.0, zoom=0.5, max_iterations=2048),                 # main cardioid, p = 1
+             dict(center_x=-1.0, center_y=0.0, zoom=0.6, max_iterations=1500),                 # period-2 disc
+             dict(center_x=-0.1225, center_y=0.7449, zoom=0.3, max_iterations=3000),           # period-3 bulb
+             dict(center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-6, max_iterations=16384),
+             dict(fractal=2, center_x=-0.5, center_y=-0.5, zoom=1.0, max_iterations=1024),     # Burning Ship hull
+             dict(fractal=1, center_x=0.0, center_y=0.0, zoom=2.0, julia_c_real=-0.12, julia_c_imag=0.74, max_iterations=2000)]
+    for kw in views:
+        for prec in (1, 0):
+            p = oracle.OracleParams(precision=prec, **kw)
+            W, H = 320, 200
+            base = gpu_render(fr, renderer, p, W, H)
+            t_off = renderer.last_kernel_ms()
+            try:
+                for opts in (dict(periodicity=1), dict(periodicity=32, pool_refill_at=1), dict(periodicity=256, pool_refill_at=64)):
+                    for k, v in opts.items():
+                        renderer.set_option(k, v)
+                    cur = gpu_render(fr, renderer, p, W, H)
+                    for a, b in zip(base, cur):
+                        assert np.array_equal(a, b), (kw, prec, opts)
+                    for k in opts:
+                        renderer.set_option(k, 0)
+                renderer.set_option("periodicity", 1)
+                shard = fr.Shard(1, 3, 8)
+                part = gpu_render(fr, renderer, p, W, H, shard=shard)
+            finally:
+                renderer.set_option("periodicity", 0)
+                renderer.set_option("pool_refill_at", 0)
+            rows = shard.global_rows(H)
+            for a, b in zip(base, part):
+                assert np.array_equal(a[rows], b)
+            assert (base[2] >= p.max_iterations).mean() > 0.2, kw          # the view really is interior-heavy
+    with pytest.raises(fr.FractalRendererError):
+        renderer.set_option("periodicity", -1)
+    # full size: the C2 frame, byte-identical and faster
+    p, W, H = oracle.OracleParams(max_iterations=1024), 4096, 4096
+    st = to_state(fr, p)
+    planes = {}
+    times = {}
+    for mode in (0, 1):
+        renderer.set_option("periodicity", mode)
+        try:
+            rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+            nu = torch.empty((H, W), dtype=torch.float64, device="cuda:0")
+            it = torch.empty((H, W), dtype=torch.int32, device="cuda:0")
+            renderer.render(st, W, H, rgba=rgba, nu=nu, iter=it)
+            ts = []
+            for _ in range(5):
+                renderer.render(st, W, H, rgba=rgba)
+                ts.append(renderer.last_kernel_ms())
+        finally:
+            renderer.set_option("periodicity", 0)
+        planes[mode] = (rgba, nu, it)
+        times[mode] = min(ts)
+    for a, b in zip(planes[0], planes[1]):
+        assert torch.equal(a, b)
+    assert times[1] < 0.85 * times[0], times
+
+
 def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
     """Work-queue geometry and the stage schedule must never change a pixel: every (workgroups/CU, run
     length, sub-tile shape, staging on/off, first budget, budget ratio) gives byte-identical planes."""
