@@ -126,6 +126,8 @@ def main() -> None:
                     help="N = 1: after the timed region, also time the same K steps with two frames in flight "
                          "(informational `pipelined` object; off by default so that a rocprofv3 trace of the "
                          "default command only contains the one-frame-at-a-time launches the roofline is quoted on)")
+    ap.add_argument("--no-periodicity", action="store_true",
+                    help="skip the informational leg with the library's exact cycle closing switched on")
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--run-max", type=int, default=0)
     ap.add_argument("--shape", type=int, default=0)
@@ -213,6 +215,28 @@ def main() -> None:
         # the phase boundaries of a frame (tile-pass tail, launch gaps, pool-pass drain) with the other frame's
         # work.  NOT the headline `value`: that stays one frame at a time, so that `roofline` keeps its
         # per-launch meaning and agrees with the rocprofv3 kernel durations.
+        # Secondary, informational: the same K steps with the library's "periodicity" option on.  The lane pool
+        # then retires an orbit as interior the moment it returns to an earlier state of its own (it can never
+        # escape: the update is a deterministic function of (z, c)); every plane stays byte-identical
+        # (tests/test_gpu_parity.py::test_periodicity_never_changes_a_pixel) but FEWER iterations are executed
+        # than the reference's shaders would run, so it is NOT the headline `value` and carries no roofline.
+        dt_cyc = None
+        if not args.no_periodicity:
+            r.set_option("periodicity", 1)
+            check = torch.empty_like(rgba)
+            r.render(state, W, H, fractal_type=ftype, precision=prec, rgba=check)
+            cyc_identical = bool(torch.equal(check, rgba))
+            del check
+            for k in range(args.warmup):
+                step(k)
+            barrier()
+            t0c = time.perf_counter()
+            for k in range(args.steps):
+                step(k)
+            barrier()
+            dt_cyc = time.perf_counter() - t0c
+            r.set_option("periodicity", 0)
+
         dt_pipe = None
         if args.pipelined:
             r2 = fr.Renderer(local_rank)
@@ -311,6 +335,14 @@ def main() -> None:
                                     "unit": "Tflop/s (8 flop per executed iteration, no FMA credit)",
                                     "frac": round(tops / peak, 4), "executed_iterations": executed,
                                     "mean_iterations_per_pixel": round(executed / (W * H), 2)}
+            if dt_cyc is not None:
+                out["periodicity"] = {"value": round(args.steps * W * H / dt_cyc / 1e6, 2), "unit": "Mpixels/s",
+                                      "ms_per_step": round(dt_cyc / args.steps * 1e3, 4),
+                                      "output_identical_to_headline_run": cyc_identical,
+                                      "note": "informational: fr_ctx_set_option(\"periodicity\", 1) -- orbits that return to an "
+                                              "earlier state of their own are retired as interior at once (exact; planes "
+                                              "byte-identical), so fewer iterations run than the reference executes; the "
+                                              "headline value above iterates every interior sample to max_iter"}
             if dt_pipe is not None:
                 out["pipelined"] = {"frames_in_flight": 2, "value": round(args.steps * W * H / dt_pipe / 1e6, 2),
                                     "unit": "Mpixels/s", "ms_per_step": round(dt_pipe / args.steps * 1e3, 4),

@@ -7,7 +7,7 @@ TAG="$1"; shift
 OUT=/root/repo/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 /root/repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline $*"
+BENCH="python3 /root/repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-periodicity $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/pmc_write.log" 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/pmc_fetch.log" 2>&1 || exit 1
