@@ -10,13 +10,16 @@ tag, workload = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(src + "/stats/**/*_kernel_stats.csv", recursive=True)[0]
+def newest(pattern):
+    """gpurun merges new files into gpurun_out/ without removing those of earlier collections: take the latest"""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+stats = newest(src + "/stats/**/*_kernel_stats.csv")
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 pmc = collections.defaultdict(dict)
 frame = collections.defaultdict(float)
 for d in ("pmc_write", "pmc_fetch", "pmc_sq_a", "pmc_sq_b"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(f"{src}/{d}/**/*_counter_collection.csv", recursive=True):
+    for f in [newest(f"{src}/{d}/**/*_counter_collection.csv")]:
         for r in csv.DictReader(open(f)):
             m = re.search(r"fr::(\w+)<([^>]*)>", r["Kernel_Name"])
             if not m:
