@@ -659,6 +659,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
             constexpr int F = decltype(f)::value == 1 ? 0 : decltype(f)::value;      /* Julia has no effects variant */
             return launch_tile<decltype(t), F, true>(shape, dim3(grid), stream, a); });
     } else {
+        /* SSAA runs every sample to max_iter in the tile pass: cycle closing applies there (escape_run) */
+        a.period_window = (p->antialiasing_samples > 1 && !staged) ? c->tune_periodicity : 0u;
         e = by_variant(fractal, f64, [&](auto t, auto f) {
             return launch_tile<decltype(t), decltype(f)::value, false>(shape, dim3(grid), stream, a); });
     }

@@ -643,10 +643,13 @@ __device__ __forceinline__ T orbit_r2x4(const Orbit<T>& o)
 /* Runs the wave's 64 orbits over iterations [i0, i1).  esc_i: escape index, i1 if the lane is
  * still alive after update i1-1 (its orbit state is then the state after i1 updates);
  * esc_r2: |z|^2 at escape.  done_in: lanes that must not run (outside the frame / empty). */
-template <typename T, bool ABS = false>
+/* PERIOD (with period_window != 0, and only when i1 is the sample's last iteration): cycle closing as in the lane
+ * pool (pool_kernel) -- a lane whose state returns to its own state at the last snapshot can never escape and is
+ * finished as "alive at i1" at once; a wave of interior samples then leaves the loop early. */
+template <typename T, bool ABS = false, bool PERIOD = false>
 __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0, const int i1,
                                            const bool fast_ok, const bool start_fast, const uint64_t done_in,
-                                           int& esc_i, T& esc_r2)
+                                           int& esc_i, T& esc_r2, const uint32_t period_window = 0u)
 {
     esc_i = i1;
     esc_r2 = T(0);
@@ -654,6 +657,26 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
     uint64_t done = done_in;
     int i = i0;                      /* wave-uniform: SGPR */
     bool fast = start_fast && fast_ok;
+    T refX = __builtin_nan(""), refYd = __builtin_nan("");
+    uint32_t snap_window = period_window, snap_closed = 1u;
+    const uint32_t snap_cap = period_window > (((uint32_t)i1 >> 7) << 4) ? period_window : (((uint32_t)i1 >> 7) << 4);
+    int next_snap = i0;
+    /* where every running lane is known not to have escaped */
+    auto close_cycles = [&]() {
+        const bool hit = o.X == refX && o.Yd == refYd;       /* finished lanes sit at 0 == 0: masked by `done` */
+        const uint64_t hm = __builtin_amdgcn_ballot_w64(hit) & ~done;
+        if (hm != 0ull) {
+            if (hit) { o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0); }
+            done |= hm;
+            snap_closed += (uint32_t)__builtin_popcountll(hm);
+        }
+        if (i >= next_snap) {
+            refX = o.X; refYd = o.Yd;
+            if (snap_closed == 0u && snap_window < snap_cap) snap_window <<= 1;
+            snap_closed = 0u;
+            next_snap = i + (int)snap_window;
+        }
+    };
 
     while (i < i1) {
         if (done == ~0ull) break;    /* every lane finished: wave-uniform early-out */
@@ -663,7 +686,11 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
 #pragma unroll
             for (int k = 0; k < kFastBlock; ++k) orbit_step<T, ABS>(o);
             const bool bad = !(orbit_r2x4(o) <= B2x4);
-            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) { i += kFastBlock; continue; }
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
+                i += kFastBlock;
+                if constexpr (PERIOD) { if (period_window) close_cycles(); }
+                continue;
+            }
             o = snap;                /* roll back, replay tested */
             fast = false;
         }
@@ -690,6 +717,7 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
         } while (i < end);
         if (done == ~0ull) return;
         fast = fast_ok && done == before;
+        if constexpr (PERIOD) { if (period_window) close_cycles(); }
     }
 }
 
@@ -884,7 +912,7 @@ tile_kernel(const LaunchArgs A)
                         /* |c| <= bailout for every live lane, else the first (tested) block
                          * retires the lane at i = 0 anyway; fast_ok also needs B^2 >= 4.5 */
                         T r2;
-                        escape_run<T>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2);
+                        escape_run<T, false, SSAA>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2, A.period_window);
                         alive = staged && inside && it >= i1;
                         if (staged) {
                             const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
@@ -996,7 +1024,7 @@ tile_kernel(const LaunchArgs A)
                         o.x2 = o.X * o.X;
                         o.y2d = o.Yd * o.Yd;
                         T r2;
-                        escape_run<T, Form<FRACTAL>::abs_step>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2);
+                        escape_run<T, Form<FRACTAL>::abs_step, SSAA>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2, A.period_window);
                         alive = staged && inside && it >= i1;
                         if (staged) {
                             const T rec4[4] = {o.X, o.Yd, o.cx, o.cyd};

@@ -230,6 +230,22 @@ def test_periodicity_on_interior_heavy_views(fr, renderer, oracle):
             for a, b in zip(base, part):
                 assert np.array_equal(a[rows], b)
             assert (base[2] >= p.max_iterations).mean() > 0.2, kw          # the view really is interior-heavy
+    # SSAA runs every sample to max_iter in the tile pass: cycles are closed there (escape_run)
+    for kw in (dict(center_x=-0.2, zoom=0.5, max_iterations=1500, aa=2), dict(max_iterations=700, aa=3),
+               dict(fractal=2, center_x=-0.5, center_y=-0.5, zoom=1.0, max_iterations=600, aa=2, precision=0),
+               dict(fractal=1, center_x=0.0, zoom=2.0, julia_c_real=-0.12, julia_c_imag=0.74, max_iterations=900, aa=2)):
+        p = oracle.OracleParams(**kw)
+        base = gpu_render(fr, renderer, p, 160, 96)
+        try:
+            for window in (1, 16, 400):
+                renderer.set_option("periodicity", window)
+                cur = gpu_render(fr, renderer, p, 160, 96)
+                for a, b in zip(base, cur):
+                    assert np.array_equal(a, b), (kw, window)
+        finally:
+            renderer.set_option("periodicity", 0)
+        ref = oracle.render(p, 160, 96)
+        check_against(p, ref.iter, ref.nu, ref.rgba, *base)
     with pytest.raises(fr.FractalRendererError):
         renderer.set_option("periodicity", -1)
     # full size: the C2 frame, byte-identical and faster

@@ -2,6 +2,9 @@ import sys, torch
 sys.path.insert(0, "/root/repo")
 import fractalrenderer_amd as fr
 r = fr.Renderer(0)
+if len(sys.argv) > 1:
+    r.set_option("periodicity", int(sys.argv[1]))      # usage: ssaa_time.py [periodicity]
+    print("periodicity", sys.argv[1])
 W = H = 4096
 out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
 for name, ft, kw in (("c2", fr.FractalType.Mandelbrot, dict(max_iterations=1024)),
