@@ -51,6 +51,10 @@ WORKLOADS = {
     "c5": dict(desc="C5 mandelbrot 8192x8192 max_iter=4096 fp64 seahorse zoom 0.008 (one .franim keyframe view)",
                fractal="Mandelbrot", precision="F64", W=8192, H=8192, cpu_rows=64,
                state=dict(max_iterations=4096, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.008)),
+    # diagnostic only (tools/timeline.py, tools/sweep_opts.py): every pixel escapes at i <= 1 -- the per-pixel skeleton
+    "far": dict(desc="diagnostic: far-exterior view, mandelbrot 4096x4096 max_iter=1024 fp64 centre (8,8) zoom 2",
+                fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=4096,
+                state=dict(max_iterations=1024, center_x=8.0, center_y=8.0, zoom=2.0)),
 }
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
