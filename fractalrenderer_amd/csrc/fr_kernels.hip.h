@@ -20,7 +20,9 @@
  *     set, max_iter inside) and a 64-pixel wave runs as long as its slowest lane (25 % lane occupancy
  *     on a Julia dust): after the tile pass every work item has bounded cost, and the expensive
  *     remainder runs dense.  (stream_kernel, block stages with x4 budgets, is the first form of the
- *     second pass, kept as an option.)
+ *     second pass, kept as an option.)  Optional PERIOD variant ("periodicity" option): a lane whose state
+ *     returns to its own snapshot is on a cycle and is retired as interior at once -- exact, the planes stay
+ *     byte-identical, but fewer iterations run than the reference executes, so it is off by default.
  *   - the iteration index is wave-uniform and lives in SGPRs; a lane that escapes records
  *     (i, |z|^2) and is parked at the fixed point z = 0, c = 0, so no per-lane "active" predicate
  *     exists in the loop; a tile wave leaves the loop as soon as the ballot of finished lanes is full
