@@ -6,9 +6,10 @@ Bars:
   * smooth iteration count nu, fp64: |dnu| <= 1e-9 asserted (the north-star tolerance is 1e-6); the
     only difference is the log() implementation (OCML vs glibc), a few ulp;
   * nu, fp32: |dnu| <= 4 ulp32(nu) + 4e-6 (same reason, in float);
-  * colour: |d| <= 2e-5 per channel (powf/expf implementations), except pixels whose palette argument
-    sits within 1e-4 of the fract() wrap, where a 1-ulp nu difference legitimately flips the colour
-    (fp32 only; the fp64 planes never hit it).
+  * colour: |d| <= 2e-5 per channel (powf/expf implementations; fp32 adds the nu tolerance times the slope
+    5 * color_scale / max_iter with which it reaches the palette -- nothing unless max_iter is a handful), except
+    pixels whose palette argument sits within 1e-4 of the fract() wrap, where a 1-ulp nu difference legitimately
+    flips the colour (fp32, one sample per pixel only; the fp64 planes never hit it).
 """
 import numpy as np
 import pytest
@@ -63,7 +64,12 @@ def check_against(p, ref_iter, ref_nu, ref_rgba, rgba, nu, it):
         assert np.all(np.abs(nu - ref_nu) <= 4 * ulp + 4e-6)
     assert np.all(rgba[..., 3] == 1.0)
     d = np.abs(rgba[..., :3] - ref_rgba[..., :3]).max(axis=-1)
-    bad = d > (RGB_TOL if not p.post_chain else 1e-4)
+    tol = RGB_TOL if not p.post_chain else 1e-4
+    if p.precision == 0:
+        # fp32: nu itself carries 4 ulp + 4e-6 (v_log_f32 against glibc logf) and reaches the palette multiplied by
+        # color_scale / max_iter (palette slope <= ~5): only visible for tiny max_iter (a soak case: max_iter = 1)
+        tol += 5.0 * abs(p.color_scale) / p.max_iterations * 8e-6
+    bad = d > tol
     if bad.any():
         assert p.precision == 0 and p.aa <= 1, "colour mismatch %g" % d.max()
         # fp32: tolerate only pixels at the fract() wrap of the palette argument

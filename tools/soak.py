@@ -13,7 +13,7 @@ rng = np.random.default_rng(seed)
 r = fr.Renderer(0)
 anchors = {0: [(-0.743643887037151, 0.13182590420533), (-0.1011, 0.9563), (-1.25066, 0.02012), (0.275, 0.0), (-0.5, 0.0), (-1.7497, 0.00001)],
            1: [(0.0, 0.0), (0.3, 0.2), (-0.6, 0.1)], 2: [(-1.755, -0.03), (-0.5, -0.5), (-1.62, -0.002)]}
-opts = ["staging", "pool_refill_at", "probes", "stream_probes", "stream_rotate", "stage_first", "subtile_shape", "workgroups_per_cu"]
+opts = ["staging", "pool_refill_at", "probes", "stream_probes", "stream_rotate", "stage_first", "subtile_shape", "workgroups_per_cu", "periodicity"]
 bad = 0
 for trial in range(trials):
     fractal = int(rng.integers(0, 3)); prec = int(rng.integers(0, 2))
@@ -24,7 +24,7 @@ for trial in range(trials):
               zoom=zoom, max_iterations=int(rng.choice([1, 33, 127, 128, 129, 300, 777, 1500, 3000, 6000])),
               bailout=float(rng.choice([1.5, 2.0, 2.5, 4.0, 4.0, 16.0, 1000.0])), palette_mode=int(rng.integers(0, 6 if fractal == 0 else 10)),
               color_offset=float(np.float32(rng.uniform(0, 1))), color_scale=float(np.float32(rng.uniform(0.5, 6))),
-              interior_style=int(rng.choice([0, 0, 1])), post_chain=int(rng.integers(0, 2)))
+              interior_style=int(rng.choice([0, 0, 1])), post_chain=int(rng.integers(0, 2)), aa=int(rng.choice([1, 1, 1, 2])))
     if fractal == 1:
         kw.update(julia_c_real=float(rng.uniform(-0.9, 0.4)), julia_c_imag=float(rng.uniform(-0.7, 0.7)))
     p = oracle.OracleParams(**kw)
@@ -34,6 +34,7 @@ for trial in range(trials):
         tune = {"staging": int(rng.choice([0, 1, 2, 3])), "pool_refill_at": int(rng.choice([0, 1, 8, 40, 64])),
                 "probes": int(rng.choice([0, 1, 2, 8])), "stream_probes": int(rng.choice([0, 1, 4, 8])), "stream_rotate": int(rng.choice([0, 1, 2])),
                 "stage_first": int(rng.choice([0, 16, 48, 160])), "subtile_shape": int(rng.choice([0, 3, 4, 6])), "workgroups_per_cu": int(rng.choice([0, 1, 3, 7]))}
+    tune["periodicity"] = int(rng.choice([0, 1, 16, 64, 1000]))            # exact cycle closing: never changes a pixel
     for k in opts: r.set_option(k, tune.get(k, 0))
     shard = None
     if trial % 3 == 1:
