@@ -38,6 +38,12 @@ _add("m_post", "mandelbrot", 16, 12, max_iterations=64, brightness=1.2, saturati
 _add("m_bailout8_ragged", "mandelbrot", 17, 9, max_iterations=80, bailout=8.0, color_scale=0.5)
 _add("m_bailout_small", "mandelbrot", 16, 12, max_iterations=64, bailout=1.5)
 
+# out-of-range selectors: the shader's switch falls back to its default branch
+_add("m_palette7_fallback", "mandelbrot", 16, 12, max_iterations=64, palette_mode=7, color_offset=0.1, color_scale=1.7)
+_add("m_interior5_fallback", "mandelbrot", 16, 12, max_iterations=48, interior_style=5)
+_add("m_aa4_offset", "mandelbrot", 6, 4, max_iterations=40, aa=4, color_offset=0.6, color_scale=3.0, palette_mode=3)
+_add("m_wide_frame", "mandelbrot", 40, 6, center_x=-0.75, center_y=0.1, zoom=1.2, max_iterations=200, palette_mode=4)
+
 # ---- shaders/julia.comp.spv --------------------------------------------------------------------------------
 _add("j_default", "julia", 64, 48, center_x=0.0, max_iterations=256)
 for _m in range(10):
@@ -47,6 +53,10 @@ _add("j_dendrite_aa2", "julia", 12, 8, center_x=0.0, max_iterations=96, julia_c_
 _add("j_rabbit_post", "julia", 20, 14, center_x=0.0, zoom=2.5, max_iterations=96, julia_c_real=-0.123, julia_c_imag=0.745,
      brightness=1.1, saturation=1.3, contrast=0.9, palette_mode=4)
 _add("j_bailout8", "julia", 16, 12, center_x=0.1, center_y=-0.2, zoom=1.5, max_iterations=80, bailout=8.0, palette_mode=6)
+
+_add("j_palette12_fallback", "julia", 16, 12, center_x=0.0, max_iterations=64, palette_mode=12, color_offset=0.15, color_scale=1.3)
+_add("j_aa3", "julia", 8, 6, center_x=0.0, max_iterations=64, aa=3, julia_c_real=0.285, julia_c_imag=0.01, palette_mode=2)
+_add("j_tall_frame", "julia", 7, 33, center_x=0.0, zoom=2.8, max_iterations=150, julia_c_real=-0.4, julia_c_imag=0.6, palette_mode=5)
 
 # ---- shaders/burning_ship.comp.spv -------------------------------------------------------------------------
 _add("s_default", "burning_ship", 64, 48, center_x=-0.5, center_y=-0.5, max_iterations=256)
@@ -64,6 +74,10 @@ for _s in (1, 2, 3):
 _add("s_aa2_post", "burning_ship", 12, 8, center_x=-0.5, center_y=-0.5, max_iterations=64, aa=2, brightness=1.1,
      saturation=0.9, contrast=1.2, palette_mode=9)
 
+_add("s_palette11_fallback", "burning_ship", 16, 12, center_x=-0.5, center_y=-0.5, max_iterations=64, palette_mode=11)
+_add("s_bailout8", "burning_ship", 18, 12, center_x=-1.755, center_y=-0.03, zoom=0.3, max_iterations=100, bailout=8.0, palette_mode=6)
+_add("s_aa3_trap", "burning_ship", 8, 6, center_x=-0.5, center_y=-0.5, max_iterations=48, aa=3, orbit_trap_enabled=1, orbit_trap_radius=0.4)
+
 # ---- shaders/test_deep_zoom.comp.spv (FractalType::Deep_Zoom) ----------------------------------------------
 _add("d_seahorse", "test_deep_zoom", 18, 10, center_x=SEAHORSE[0], center_y=SEAHORSE[1], zoom=1e-6, max_iterations=1200,
      use_perturbation=1)
@@ -75,3 +89,5 @@ _add("d_no_perturbation", "test_deep_zoom", 14, 10, center_x=-0.6, center_y=0.2,
      use_perturbation=0, palette_mode=2)
 _add("d_gray_small_bailout", "test_deep_zoom", 12, 12, center_x=-0.1, center_y=0.65, zoom=120.0, max_iterations=90,
      use_perturbation=1, palette_mode=7, bailout=1.0)
+_add("d_palette3_bailout4", "test_deep_zoom", 14, 10, center_x=-0.75, center_y=0.1, zoom=60.0, max_iterations=150,
+     use_perturbation=1, palette_mode=3, bailout=4.0, color_scale=0.7)
