@@ -26,6 +26,7 @@ from fractalrenderer_amd.distributed import pick_rows_per_strip
 shard = fr.Shard(0, nparts, pick_rows_per_strip(H, nparts)) if nparts > 1 else None
 rows = shard.rows(H) if shard else H
 out = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda:0") if plane == "rgba" else \
+    torch.empty((rows, W), dtype=torch.int32, device="cuda:0") if plane == "iter" else \
     torch.empty((rows, W), dtype=torch.float64 if w["precision"] == "F64" else torch.float32, device="cuda:0")
 kw = dict(fractal_type=fr.FractalType[w["fractal"]], precision=fr.Precision[w["precision"]], shard=shard, **{plane: out})
 state = fr.FractalState(**st)
