@@ -302,6 +302,16 @@ def main() -> None:
         dt = time.perf_counter() - t0
         last_ms = r.last_kernel_ms()
         lane_ms = [c.last_kernel_ms() for c in ctxs]     # device time of each render context's last launch
+        # outside the timed region: one more group, and every rank compares the frame it was handed with a direct
+        # single-GPU render of the same frame (bitwise); the verdict of all ranks goes into the JSON line
+        slot = fx.submit_group(render_fn, 0, world, colorize_fn if payload == "nu" else None)
+        fx.drain()
+        direct = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+        r.render(state, W, H, fractal_type=ftype, precision=prec, rgba=direct)
+        ok = torch.tensor([1 if torch.equal(fx.frame_rgba[slot], direct) else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        exchange_verified = bool(ok.item())
+        del direct
 
     # MAX over ranks
     if world > 1:
@@ -368,6 +378,7 @@ def main() -> None:
             bpp = 16 if payload == "rgba" else (8 if prec == fr.Precision.F64 else 4)
             bytes_per_launch = bpp * W * fx.rows_local
             gbs = bytes_per_launch / (sum(ms) / len(ms) * 1e-3) / 1e9 if ms else 0.0
+            out["exchange_verified"] = exchange_verified     # gathered frames == direct single-GPU render, on every rank
             out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
                                "kernel_ms": round(sum(ms) / len(ms), 4) if ms else None,
