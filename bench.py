@@ -38,6 +38,8 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (fractal, precision, W, H, state kwargs)
+    "c1": dict(desc="C1 mandelbrot 512x512 max_iter=256 fp64 default viewport (BASELINE.json configs[0], the CPU-runnable case)",
+               fractal="Mandelbrot", precision="F64", W=512, H=512, cpu_rows=512, cpu_passes=20, state=dict(max_iterations=256)),
     "c2": dict(desc="C2 mandelbrot 4096x4096 max_iter=1024 fp64 default viewport (center -0.5,0 zoom 3.0)",
                fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=4096, state=dict(max_iterations=1024)),
     "c2_reset": dict(desc="mandelbrot 4096x4096 max_iter=1024 fp64 reset() viewport (zoom 1.5)",
@@ -51,6 +53,12 @@ WORKLOADS = {
     "c5": dict(desc="C5 mandelbrot 8192x8192 max_iter=4096 fp64 seahorse zoom 0.008 (one .franim keyframe view)",
                fractal="Mandelbrot", precision="F64", W=8192, H=8192, cpu_rows=64,
                state=dict(max_iterations=4096, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.008)),
+    "hd": dict(desc="interactive size: mandelbrot 1920x1080 max_iter=256 fp32 default viewport (the reference's draw loop)",
+               fractal="Mandelbrot", precision="F32", W=1920, H=1080, cpu_rows=1080, state=dict(max_iterations=256)),
+    "uhd": dict(desc="interactive size: mandelbrot 3840x2160 max_iter=256 fp32 default viewport",
+                fractal="Mandelbrot", precision="F32", W=3840, H=2160, cpu_rows=2160, state=dict(max_iterations=256)),
+    "uhd1k": dict(desc="interactive size: mandelbrot 3840x2160 max_iter=1024 fp64 default viewport",
+                  fractal="Mandelbrot", precision="F64", W=3840, H=2160, cpu_rows=2160, state=dict(max_iterations=1024)),
     # diagnostic only (tools/timeline.py, tools/sweep_opts.py): every pixel escapes at i <= 1 -- the per-pixel skeleton
     "far": dict(desc="diagnostic: far-exterior view, mandelbrot 4096x4096 max_iter=1024 fp64 centre (8,8) zoom 2",
                 fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=4096,

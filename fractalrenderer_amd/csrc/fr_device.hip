@@ -434,7 +434,7 @@ static bool needs_effects(const fr_params* p)
  * Sub-tiles of 64 pixels (2^shape wide) in blocks of 16 dealt round-robin to the 8 shards over a
  * power-of-two padded block index space (optionally bit-reversed; blocks >= n_blk are skipped by the
  * kernel); a persistent grid of exactly the resident set; run lengths and probe limit of the queue. */
-static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_local, int shape, bool bounded,
+static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_local, int shape, bool bounded, bool moderate,
                                  uint32_t* grid_out, uint32_t* waves_per_shard_out)
 {
     const uint32_t fpw = 1u << shape, fph = 64u >> shape;
@@ -456,7 +456,11 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
      * kernel fits 7 at 69 VGPRs) within 1 %. */
     const uint32_t wg_per_cu = c->tune_wg_per_cu ? c->tune_wg_per_cu : 5u;
     uint32_t grid = (uint32_t)c->compute_units * wg_per_cu;
-    const uint32_t max_grid = (tq.n_items + 3) / 4;        /* never more waves than sub-tiles */
+    /* never more waves than the shortest runs can feed: a wave takes at least run_min sub-tiles per dequeue (4 when
+     * bounded, 2 otherwise), and waves that find nothing still cost their launch and their exit probes -- at 512^2
+     * a grid of one wave per sub-tile left 3 of 4 waves without work: 0.083 ms per frame against 0.048 ms */
+    const uint32_t per_wave = c->tune_run_min ? c->tune_run_min : (bounded ? 4u : 2u);
+    const uint32_t max_grid = (tq.n_items + 4u * per_wave - 1u) / (4u * per_wave);
     if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
     const uint32_t waves_per_shard = (grid * 4u + kShards - 1) / kShards;
     auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
@@ -481,7 +485,7 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
      * probing the other 7 (measured: the exit storm of 4096 waves x 8 serialized atomics costs 31 us of the
      * 260 us tile pass of C2 and 36 of the 74 us of a 1/8 shard, profiles/r01_probe_limit.txt).  Unbounded
      * passes keep full stealing; so do grids with fewer workgroups than shards. */
-    uint32_t probes = c->tune_probes ? c->tune_probes : ((bounded && grid >= 64u) ? 1u : 0u);
+    uint32_t probes = c->tune_probes ? c->tune_probes : (((bounded || moderate) && grid >= 64u) ? 1u : 0u);
     if (grid < (uint32_t)kShards) probes = 0;
     tq.flags |= probes << kQueueProbeShift;
     *grid_out = grid;
@@ -494,7 +498,7 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
  * (lane pool, "staging" = 3, the default).  Not staged: SSAA (samples of a pixel must meet again to be
  * averaged), the effects variants (accumulators along the whole orbit), short max_iter.  Returns the
  * number of passes; bounds[k] = upper iteration bound of pass k. */
-static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, int bounds[kMaxStages])
+static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t npx, int bounds[kMaxStages])
 {
     const int max_iter = p->max_iterations;
     int nstage = 0;
@@ -508,9 +512,14 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, int bo
     auto_first = auto_first < 32 ? 32 : (auto_first > 192 ? 192 : auto_first);
     const int first = c->tune_stage_first ? (int)c->tune_stage_first : auto_first;
     const int ratio = c->tune_stage_ratio >= 2 ? (int)c->tune_stage_ratio : 4;
-    /* below ~4 budgets the second launch costs more than it balances (measured at max_iter 64: 0.32 ms
-     * staged, 0.25 ms as one bounded pass) */
-    if (allow && max_iter >= (c->tune_stage_first ? 2 : 4) * first) {
+    /* The second pass pays off where orbits are long: below max_iter ~768 (~384 on frames above 4K) ONE pass whose
+     * waves stop at their home shard is faster -- 1080p at max_iter 256: 0.061 ms against 0.109 ms, the Seahorse view
+     * at 4096^2 / 256: 0.69 against 1.02 ms (nearly every pixel survives the tile pass there and is handled twice);
+     * above it the two passes win by up to 35 % (profiles/r01_staging_crossover.txt).  An explicit "staging" or
+     * "stage_first" option keeps the old rule (at least 2 budgets). */
+    const int auto_min = npx > ((size_t)1 << 23) ? 384 : 768;
+    const bool forced = c->tune_staging != 0 || c->tune_stage_first != 0;
+    if (allow && (forced ? max_iter >= 2 * first : max_iter >= auto_min)) {
         long long b = first - first % kFastBlock;                /* budgets are multiples of the unchecked block */
         if (b < kFastBlock) b = kFastBlock;
         while (b < max_iter && nstage < kMaxStages - 1) {
@@ -598,7 +607,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.exact_div_ok = exact_division_ok(c, W, H, uv_map, f64) ? 1 : 0;
 
     int bounds[kMaxStages];
-    const int nstage = plan_stages(c, p, effects, bounds);
+    const int nstage = plan_stages(c, p, effects, (size_t)rows_local * W, bounds);
     const bool staged = nstage > 1;
     /* survivor-stream writers move to the next region after every block: the 8 regions come out equally
      * long with the same mix of blocks, so the reading pass is balanced with little stealing (measured,
@@ -610,16 +619,24 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      * (measured at max_iter <= 32: 0.31 ms with short runs -- the queue words saturate -- 0.17 ms with long) */
     const int aa1 = p->antialiasing_samples > 1 ? p->antialiasing_samples : 1;
     const bool bounded = staged || (!effects && (long long)max_iter * aa1 * aa1 <= 128);
+    /* items of moderate cost (an unstaged pass below the staging threshold): short runs as for unbounded items, but
+     * the waves stop at their home shard -- the blocks of 16 sub-tiles dealt round-robin keep the shards level */
+    const bool moderate = !staged && !effects && (long long)max_iter * aa1 * aa1 < 768;
     const int shape = c->tune_shape ? (int)c->tune_shape : 3;
     uint32_t grid = 0, waves_per_shard = 0;
-    const QueueArgs tq = plan_tile_queue(c, W, rows_local, shape, bounded, &grid, &waves_per_shard);
+    const QueueArgs tq = plan_tile_queue(c, W, rows_local, shape, bounded, moderate, &grid, &waves_per_shard);
     auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
     c->last_grid = grid;
 
     /* ---- survivor streams in context scratch ------------------------------------------------------------ */
     /* the pool / stream kernels hold 6 workgroups per CU; their blocks are latency bound (dequeue -> record
      * loads -> iterate -> scattered stores), so run all of them */
-    const uint32_t sgrid = (uint32_t)c->compute_units * (c->tune_stream_wg_per_cu ? c->tune_stream_wg_per_cu : 6u);
+    uint32_t sgrid = (uint32_t)c->compute_units * (c->tune_stream_wg_per_cu ? c->tune_stream_wg_per_cu : 6u);
+    {   /* small frames: at most one wave per 4 sub-tiles of the frame (every survivor block holds 64 records, and
+         * a frame rarely leaves more than a quarter of its pixels alive after the tile pass) */
+        const uint32_t cap = (tq.n_items + 15u) / 16u;
+        if (sgrid > cap) sgrid = cap < 1u ? 1u : cap;
+    }
     uint32_t region_blocks = 0;
     if (staged) {
         const int st = reserve_streams(c, (size_t)rows_local * W, julia ? 2 : 4, f64, grid > sgrid ? grid : sgrid,

@@ -208,7 +208,9 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                        slower and were removed); accepted and ignored
  *   "staging"            3 = tile pass for the first "stage_first" iterations + ONE lane-pool pass over the
  *                        compacted survivors to max_iter, 2 = tile pass + block stream passes, 1 = single pass,
- *                        0 = automatic (= 3 wherever it applies: no SSAA, no trap/stripe effects)
+ *                        0 = automatic: 3 where it applies (no SSAA, no trap/stripe effects) and pays off --
+ *                        max_iterations >= 768, or >= 384 on frames above 2^23 pixels; below that one pass whose
+ *                        waves stop at their home queue shard is faster (profiles/r01_staging_crossover.txt)
  *   "stage_first"        iteration budget of the tile pass (default ~max_iter/28 within [32, 192])
  *   "stage_ratio"        budget growth per stream pass (default 4)
  *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue may claim in a stream pass
