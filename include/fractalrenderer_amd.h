@@ -218,7 +218,8 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "queue_flags"        retired: bit-reversed tile order and claim-ahead measured slower everywhere and were
  *                        removed from the kernels; the option is accepted and ignored
  *   "probes", "stream_probes"  queue shards a wave tries before it exits, tile pass / stream passes
- *                        (1..8; 0 = automatic: 1 for a staged tile pass, 4 for its stream passes, 8 otherwise)
+ *                        (1..8; 0 = automatic: 1 for a staged or short-orbit tile pass, 4 for stream passes,
+ *                        all 8 otherwise and on grids of fewer than 64 workgroups)
  *   "stream_rotate"      2 = survivor-stream writers rotate over the 8 regions (equal regions), 1 = one region
  *                        per XCD, 0 = automatic (= 2)
  *   "periodicity"        0 = off (default), 1 = on, N > 1 = on with a first snapshot window of N iterations.
