@@ -730,8 +730,12 @@ __device__ __forceinline__ void escape_run_effects(T& zx, T& zy, const T cx, con
                                                    const int max_iter, const uint64_t done_in,
                                                    int& esc_i, T& esc_zx, T& esc_zy, T& min_trap)
 {
+    /* The shader takes, every iteration, the minimum of length(z), min(|z.x|, |z.y|) and length(z - c) into minTrap
+     * (shaders/mandelbrot.comp:163-166).  A correctly rounded square root is monotonic, so
+     * min_i sqrt(a_i) == sqrt(min_i a_i) bit for bit: the loop keeps the minima of the SQUARED lengths and takes the
+     * two square roots once, after it -- 2 x ~25 fp64 instructions less per iteration, same minTrap. */
     esc_i = max_iter;
-    min_trap = T(1e20);
+    T m_origin2 = (T)__builtin_inff(), m_axes = T(1e20), m_c2 = (T)__builtin_inff();
     bool live = true;
     uint64_t done = done_in;
     for (int i = 0; i < max_iter; ++i) {
@@ -740,15 +744,16 @@ __device__ __forceinline__ void escape_run_effects(T& zx, T& zy, const T cx, con
         const T y = T(2) * zx * zy + cy;
         if (live) {
             zx = x; zy = y;
-            const T d_origin = Real<T>::sqrt(zx * zx + zy * zy);
-            const T d_axes = Real<T>::fmin(Real<T>::fabs(zx), Real<T>::fabs(zy));
+            const T r2 = zx * zx + zy * zy;
             const T dx = zx - cx, dy = zy - cy;
-            const T d_c = Real<T>::sqrt(dx * dx + dy * dy);
-            min_trap = Real<T>::fmin(min_trap, Real<T>::fmin(d_origin, Real<T>::fmin(d_axes, d_c)));
-            if (zx * zx + zy * zy > B2) { esc_i = i; live = false; }
+            m_origin2 = Real<T>::fmin(m_origin2, r2);
+            m_axes = Real<T>::fmin(m_axes, Real<T>::fmin(Real<T>::fabs(zx), Real<T>::fabs(zy)));
+            m_c2 = Real<T>::fmin(m_c2, dx * dx + dy * dy);
+            if (r2 > B2) { esc_i = i; live = false; }
         }
         done |= __builtin_amdgcn_ballot_w64(!live);
     }
+    min_trap = Real<T>::fmin(T(1e20), Real<T>::fmin(Real<T>::sqrt(m_origin2), Real<T>::fmin(m_axes, Real<T>::sqrt(m_c2))));
     esc_zx = zx; esc_zy = zy;
 }
 
