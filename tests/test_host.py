@@ -550,3 +550,19 @@ def test_host_code_under_sanitizers(golden, tmp_path, monkeypatch):
         assert run.returncode == 0 and "ERROR" not in run.stderr and "WARNING: ThreadSanitizer" not in run.stderr \
             and "runtime error" not in run.stderr, (tag, run.stderr[-3000:])
         assert run.stdout.startswith("parsed ok")
+
+
+def test_bench_workloads_and_cpu_baseline_leg(oracle):
+    """bench.py's workload table is well formed (the tools import it too) and its cpu_baseline leg -- the oracle timed
+    on the host cores -- returns the contract's object on a bounded sample (here: the C1 frame)."""
+    import bench
+    for name, w in bench.WORKLOADS.items():
+        assert {"desc", "fractal", "precision", "W", "H", "state"} <= set(w), name
+        assert w["fractal"] in ("Mandelbrot", "JuliaSet") and w["precision"] in ("F64", "F32"), name
+        assert w["state"]["max_iterations"] >= 1 and w["W"] > 0 and w["H"] > 0
+    assert bench.WORKLOADS["c2"]["W"] == bench.WORKLOADS["c2"]["H"] == 4096
+    assert bench.WORKLOADS["c2"]["state"] == {"max_iterations": 1024} and bench.WORKLOADS["c2"]["precision"] == "F64"
+    w = dict(bench.WORKLOADS["c1"], cpu_passes=1)
+    b = bench.cpu_baseline(w)
+    assert b["kind"] == "port" and b["unit"] == "Mpixels/s" and b["cores"] >= 1 and b["value"] > 0
+    assert "sample" in b and "oracle" in b["sample"]
