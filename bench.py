@@ -55,6 +55,8 @@ WORKLOADS = {
                state=dict(max_iterations=4096, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.008)),
     "hd": dict(desc="interactive size: mandelbrot 1920x1080 max_iter=256 fp32 default viewport (the reference's draw loop)",
                fractal="Mandelbrot", precision="F32", W=1920, H=1080, cpu_rows=1080, state=dict(max_iterations=256)),
+    "hd1k": dict(desc="interactive size: mandelbrot 1920x1080 max_iter=1024 fp64 default viewport",
+                 fractal="Mandelbrot", precision="F64", W=1920, H=1080, cpu_rows=1080, state=dict(max_iterations=1024)),
     "uhd": dict(desc="interactive size: mandelbrot 3840x2160 max_iter=256 fp32 default viewport",
                 fractal="Mandelbrot", precision="F32", W=3840, H=2160, cpu_rows=2160, state=dict(max_iterations=256)),
     "uhd1k": dict(desc="interactive size: mandelbrot 3840x2160 max_iter=1024 fp64 default viewport",

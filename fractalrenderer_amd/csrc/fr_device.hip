@@ -634,9 +634,10 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     /* the pool / stream kernels hold 6 workgroups per CU; their blocks are latency bound (dequeue -> record
      * loads -> iterate -> scattered stores), so run all of them */
     uint32_t sgrid = (uint32_t)c->compute_units * (c->tune_stream_wg_per_cu ? c->tune_stream_wg_per_cu : 6u);
-    {   /* small frames: at most one wave per 4 sub-tiles of the frame (every survivor block holds 64 records, and
-         * a frame rarely leaves more than a quarter of its pixels alive after the tile pass) */
-        const uint32_t cap = (tq.n_items + 15u) / 16u;
+    {   /* small frames: at most one wave per 8 sub-tiles of the frame (every survivor block holds 64 records, and
+         * a frame rarely leaves more than a quarter of its pixels alive after the tile pass: ~2 blocks per wave;
+         * 1080p at max_iter 1024: 0.144 ms with 6 workgroups per CU, 0.128 ms with the 4 this cap gives) */
+        const uint32_t cap = (tq.n_items + 31u) / 32u;
         if (sgrid > cap) sgrid = cap < 1u ? 1u : cap;
     }
     uint32_t region_blocks = 0;
