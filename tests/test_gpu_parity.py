@@ -9,7 +9,9 @@ Bars:
   * colour: |d| <= 2e-5 per channel (powf/expf implementations; fp32 adds the nu tolerance times the slope
     5 * color_scale / max_iter with which it reaches the palette -- nothing unless max_iter is a handful), except
     pixels whose palette argument sits within 1e-4 of the fract() wrap, where a 1-ulp nu difference legitimately
-    flips the colour (fp32, one sample per pixel only; the fp64 planes never hit it).
+    flips the colour (fp32, one sample per pixel only; the fp64 planes never hit it).  With the post chain the bar
+    is 1e-4, and pixels next to black, where the final pow(c, 1/2.2) has unbounded slope, are compared before the
+    gamma (1e-6).
 """
 import numpy as np
 import pytest
