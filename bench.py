@@ -53,6 +53,9 @@ WORKLOADS = {
     "c5": dict(desc="C5 mandelbrot 8192x8192 max_iter=4096 fp64 seahorse zoom 0.008 (one .franim keyframe view)",
                fractal="Mandelbrot", precision="F64", W=8192, H=8192, cpu_rows=64,
                state=dict(max_iterations=4096, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.008)),
+    "rabbit": dict(desc="julia c=-0.123+0.745i (Douady rabbit: attracting 3-cycle, filled interior) 4096x4096 max_iter=2048 fp32",
+                   fractal="JuliaSet", precision="F32", W=4096, H=4096, cpu_rows=512,
+                   state=dict(max_iterations=2048, center_x=0.0, center_y=0.0, julia_c_real=-0.123, julia_c_imag=0.745)),
     "hd": dict(desc="interactive size: mandelbrot 1920x1080 max_iter=256 fp32 default viewport (the reference's draw loop)",
                fractal="Mandelbrot", precision="F32", W=1920, H=1080, cpu_rows=1080, state=dict(max_iterations=256)),
     "hd1k": dict(desc="interactive size: mandelbrot 1920x1080 max_iter=1024 fp64 default viewport",
