@@ -268,6 +268,14 @@ static hipError_t launch_tile_aa(int shape, dim3 grid, hipStream_t s, const Laun
 template <typename T, int FRACTAL, bool EFFECTS>
 static hipError_t launch_tile(int shape, dim3 grid, hipStream_t s, const LaunchArgs& a)
 {
+    if constexpr (!EFFECTS) {
+        /* one-sample pass run to max_iter with cycle closing on: its own variant (8x8 sub-tiles only), so that the
+         * default kernel does not carry the snapshot registers */
+        if (a.aa <= 1 && a.period_window && shape == 3) {
+            hipLaunchKernelGGL((tile_kernel<T, FRACTAL, 3, false, false, true>), grid, dim3(kBlockThreads), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     return a.aa > 1 ? launch_tile_aa<T, FRACTAL, EFFECTS, true>(shape, grid, s, a)
                     : launch_tile_aa<T, FRACTAL, EFFECTS, false>(shape, grid, s, a);
 }
@@ -680,7 +688,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
             return launch_tile<decltype(t), F, true>(shape, dim3(grid), stream, a); });
     } else {
         /* SSAA runs every sample to max_iter in the tile pass: cycle closing applies there (escape_run) */
-        a.period_window = (p->antialiasing_samples > 1 && !staged) ? c->tune_periodicity : 0u;
+        a.period_window = !staged ? c->tune_periodicity : 0u;          /* a staged tile pass hands its survivors on */
         e = by_variant(fractal, f64, [&](auto t, auto f) {
             return launch_tile<decltype(t), decltype(f)::value, false>(shape, dim3(grid), stream, a); });
     }

@@ -812,10 +812,13 @@ __device__ __forceinline__ void diag_write(const LaunchArgs& A, uint32_t lane, u
  * FRACTAL: 0 Mandelbrot, 1 Julia, 2 Burning Ship.  FPW_LOG2: log2 of the sub-tile width (3: 8x8, 4: 16x4, 6: 64x1).
  * EFFECTS: trap / stripe / interior-style variant (Mandelbrot and Burning Ship, never staged).
  * Runs iterations [0, A.i1); when A.i1 < max_iter the samples still alive go to A.out. */
-template <typename T, int FRACTAL, int FPW_LOG2, bool EFFECTS, bool SSAA>
+template <typename T, int FRACTAL, int FPW_LOG2, bool EFFECTS, bool SSAA, bool PERIOD = false>
 __global__ void __launch_bounds__(kBlockThreads)
 tile_kernel(const LaunchArgs A)
 {
+    /* cycle closing in escape_run: always compiled into the SSAA variants, and into the PERIOD variant of the
+     * one-sample kernel (an unstaged pass with the "periodicity" option on); the default one-sample kernel stays lean */
+    constexpr bool CLOSE = SSAA || PERIOD;
     constexpr int FPW = 1 << FPW_LOG2;
     constexpr int FPH = kWave / FPW;
     constexpr int NF = RecFields<FRACTAL>::n;
@@ -919,7 +922,7 @@ tile_kernel(const LaunchArgs A)
                         /* |c| <= bailout for every live lane, else the first (tested) block
                          * retires the lane at i = 0 anyway; fast_ok also needs B^2 >= 4.5 */
                         T r2;
-                        escape_run<T, false, SSAA>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2, A.period_window);
+                        escape_run<T, false, CLOSE>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2, A.period_window);
                         alive = staged && inside && it >= i1;
                         if (staged) {
                             const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
@@ -1031,7 +1034,7 @@ tile_kernel(const LaunchArgs A)
                         o.x2 = o.X * o.X;
                         o.y2d = o.Yd * o.Yd;
                         T r2;
-                        escape_run<T, Form<FRACTAL>::abs_step, SSAA>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2, A.period_window);
+                        escape_run<T, Form<FRACTAL>::abs_step, CLOSE>(o, B2, 0, i1, A.fast_ok != 0, false, outside_mask, it, r2, A.period_window);
                         alive = staged && inside && it >= i1;
                         if (staged) {
                             const T rec4[4] = {o.X, o.Yd, o.cx, o.cyd};

@@ -223,7 +223,8 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "stream_rotate"      2 = survivor-stream writers rotate over the 8 regions (equal regions), 1 = one region
  *                        per XCD, 0 = automatic (= 2)
  *   "periodicity"        0 = off (default), 1 = on, N > 1 = on with a first snapshot window of N iterations.
- *                        The lane-pool pass keeps, per lane, the orbit state at the last snapshot; a lane whose
+ *                        The lane-pool pass (and the tile pass where it runs samples to max_iterations: SSAA, and
+ *                        one-pass frames with 8x8 sub-tiles) keeps, per lane, the orbit state at the last snapshot; a lane whose
  *                        state returns to it is on a cycle, can never escape, and is retired as interior at once
  *                        instead of being iterated to max_iter.  Exact, not a heuristic: the update is a
  *                        deterministic function of (z, c), so every plane stays byte-identical

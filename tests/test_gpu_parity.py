@@ -203,11 +203,14 @@ def test_periodicity_never_changes_a_pixel(fr, renderer, oracle, name, window):
         renderer.set_option("staging", 3)            # cycles are closed in the lane-pool pass: run it whatever max_iter is
         cur = gpu_render(fr, renderer, p, W, H)
         assert renderer.last_stages() == 2
+        renderer.set_option("staging", 1)            # ... and in the tile kernel of a one-pass frame
+        one = gpu_render(fr, renderer, p, W, H)
+        assert renderer.last_stages() == 1
     finally:
         renderer.set_option("periodicity", 0)
         renderer.set_option("staging", 0)
-    for a, b in zip(base, cur):
-        assert np.array_equal(a, b)
+    for a, b, c in zip(base, cur, one):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
     ref = oracle.render(p, W, H)
     check_against(p, ref.iter, ref.nu, ref.rgba, *cur)
 
@@ -229,7 +232,9 @@ def test_periodicity_on_interior_heavy_views(fr, renderer, oracle):
             base = gpu_render(fr, renderer, p, W, H)
             t_off = renderer.last_kernel_ms()
             try:
-                for opts in (dict(periodicity=1), dict(periodicity=32, pool_refill_at=1), dict(periodicity=256, pool_refill_at=64)):
+                for opts in (dict(periodicity=1), dict(periodicity=32, pool_refill_at=1), dict(periodicity=256, pool_refill_at=64),
+                             dict(periodicity=1, staging=1),                         # one pass: cycles closed in the tile kernel
+                             dict(periodicity=16, staging=1, subtile_shape=4)):      # ... which only exists for 8x8 sub-tiles
                     for k, v in opts.items():
                         renderer.set_option(k, v)
                     cur = gpu_render(fr, renderer, p, W, H)
