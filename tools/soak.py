@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Longer randomised parity soak (not part of the test suite): usage soak.py [trials] [seed]"""
+"""Longer randomised parity soak (not part of the test suite): usage soak.py [trials] [seed] [size scale]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,6 +9,7 @@ from oracle import oracle
 import test_gpu_parity as T
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # frame sizes up to 420*scale x 300*scale
 rng = np.random.default_rng(seed)
 r = fr.Renderer(0)
 anchors = {0: [(-0.743643887037151, 0.13182590420533), (-0.1011, 0.9563), (-1.25066, 0.02012), (0.275, 0.0), (-0.5, 0.0), (-1.7497, 0.00001)],
@@ -19,7 +20,7 @@ for trial in range(trials):
     fractal = int(rng.integers(0, 3)); prec = int(rng.integers(0, 2))
     ax, ay = anchors[fractal][int(rng.integers(0, len(anchors[fractal])))]
     zoom = float(10.0 ** rng.uniform(-5.0 if prec == 1 else -2.0, 0.6))
-    W, H = int(rng.integers(9, 420)), int(rng.integers(5, 300))
+    W, H = int(rng.integers(9, 420 * scale)), int(rng.integers(5, 300 * scale))
     kw = dict(fractal=fractal, precision=prec, center_x=ax + zoom * float(rng.uniform(-0.2, 0.2)), center_y=ay + zoom * float(rng.uniform(-0.2, 0.2)),
               zoom=zoom, max_iterations=int(rng.choice([1, 33, 127, 128, 129, 300, 777, 1500, 3000, 6000])),
               bailout=float(rng.choice([1.5, 2.0, 2.5, 4.0, 4.0, 16.0, 1000.0])), palette_mode=int(rng.integers(0, 6 if fractal == 0 else 10)),
