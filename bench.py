@@ -151,6 +151,9 @@ def main() -> None:
     ap.add_argument("--rows-per-strip", type=int, default=0)
     ap.add_argument("--payload", default="auto", choices=["auto", "nu", "rgba"],
                     help="N > 1: plane shipped over xGMI (auto: nu when the colour is a function of nu)")
+    ap.add_argument("--layout", default="bands", choices=["bands", "strips"],
+                    help="N > 1: contiguous row bands that rotate over the frames of a group and are received in place "
+                         "(default), or row strips interleaved inside every frame")
     ap.add_argument("--render-lanes", type=int, default=0,
                     help="N > 1: concurrent render contexts/streams per rank (0: min(4, N))")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsals only: gloo + --same-device on one card")
@@ -283,7 +286,7 @@ def main() -> None:
         nu_dtype = torch.float64 if prec == fr.Precision.F64 else torch.float32
         lanes = args.render_lanes or min(4, world)
         fx = FrameExchange(W, H, payload=payload, nu_dtype=nu_dtype, device=dev, rows_per_strip=args.rows_per_strip,
-                           render_lanes=lanes)
+                           render_lanes=lanes, layout=args.layout)
         # one render context per lane: a context is not re-entrant, distinct contexts run concurrently
         ctxs = [r] + [fr.Renderer(local_rank) for _ in range(lanes - 1)]
         for c in ctxs[1:]:
@@ -342,7 +345,10 @@ def main() -> None:
             "scaling": "strong",
             "vs_baseline": None, "dtype": "f64" if prec == fr.Precision.F64 else "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "output": "RGBA f32 linear colour, 16 B/pixel, resident in HBM",
-                       "parallelism": (f"row strips of {fx.R} rows round-robin over {world} GPUs; frames in groups of {world}, "
+                       "parallelism": ((f"disjoint row bands of {fx.R} rows, one per GPU and frame, the band of a GPU rotating over "
+                                        f"the frames of a group; " if fx.bands else
+                                        f"row strips of {fx.R} rows round-robin over {world} GPUs; ") +
+                                       f"frames in groups of {world}, "
                                        f"frame g*{world}+j gathered to rank j by one RCCL all-to-all per group "
                                        f"(payload: {payload} plane, {'recoloured at the destination, ' if payload == 'nu' else ''}"
                                        f"double-buffered, {lanes} concurrent render contexts per rank)" if world > 1

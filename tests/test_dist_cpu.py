@@ -76,14 +76,16 @@ def test_pick_rows_per_strip(fr):
     assert pick_rows_per_strip(7, 8) == 1 and pick_rows_per_strip(1000, 3) == 1
 
 
-def _fx_worker(rank, world, port, W, H, R, payload, nframes, q):
+def _fx_worker(rank, world, port, W, H, R, payload, nframes, q, layout="strips"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from fractalrenderer_amd.distributed import FrameExchange
         from oracle import oracle as O
-        fx = FrameExchange(W, H, payload=payload, nu_dtype=torch.float64, device=torch.device("cpu"), rows_per_strip=R)
+        fx = FrameExchange(W, H, payload=payload, nu_dtype=torch.float64, device=torch.device("cpu"), rows_per_strip=R,
+                           layout=layout)
+        assert fx.bands == (layout == "bands" and H % world == 0)
         params = lambda f: O.OracleParams(max_iterations=48 + 16 * f, palette_mode=f % 6, center_x=-0.5 - 0.01 * f)  # noqa: E731
 
         def render_fn(shard, out, frame, plane, lane=0):
@@ -119,16 +121,19 @@ def _fx_worker(rank, world, port, W, H, R, payload, nframes, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,W,H,R,payload,nframes", [(2, 40, 32, 4, "nu", 4), (2, 24, 23, 5, "rgba", 3),
-                                                         (3, 16, 30, 0, "nu", 7), (3, 8, 2, 1, "nu", 3),
-                                                         (2, 24, 23, 5, "nu", 5)])
-def test_frame_exchange_gloo(oracle, fr, world, W, H, R, payload, nframes):
+@pytest.mark.parametrize("world,W,H,R,payload,nframes,layout", [
+    (2, 40, 32, 4, "nu", 4, "strips"), (2, 24, 23, 5, "rgba", 3, "strips"), (3, 16, 30, 0, "nu", 7, "strips"),
+    (3, 8, 2, 1, "nu", 3, "strips"), (2, 24, 23, 5, "nu", 5, "strips"),
+    # rotating bands: rank r renders band (r + j) mod N of frame j, bands are received in place
+    (2, 40, 32, 0, "nu", 5, "bands"), (3, 16, 30, 0, "rgba", 7, "bands"), (3, 12, 9, 0, "nu", 4, "bands"),
+    (2, 24, 23, 5, "nu", 3, "bands")])                      # H % N != 0: falls back to strips
+def test_frame_exchange_gloo(oracle, fr, world, W, H, R, payload, nframes, layout):
     """Rotating-root exchange: frame g*world + j must land, complete and bit-identical to a whole-frame
-    render, on rank j -- even and ragged strip layouts, partial last group, ranks that own no rows."""
+    render, on rank j -- even and ragged strip layouts, rotating bands, partial last group, ranks that own no rows."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_fx_worker, args=(r, world, port, W, H, R, payload, nframes, q)) for r in range(world)]
+    procs = [ctx.Process(target=_fx_worker, args=(r, world, port, W, H, R, payload, nframes, q, layout)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -695,7 +695,7 @@ def test_frame_exchange_single_rank_on_gpu(fr, renderer, oracle):
         fx.drain()
 
 
-def _fx_gpu_worker(rank, world, port, q):
+def _fx_gpu_worker(rank, world, port, q, layout="strips"):
     import os
     import sys
     import torch
@@ -713,8 +713,8 @@ def _fx_gpu_worker(rank, world, port, q):
         r = fr.Renderer(0)
         r2 = fr.Renderer(0)                                          # second render context for lane 1
         states = [fr.FractalState(max_iterations=200 + 40 * k, zoom=3.0 - 0.2 * k) for k in range(nframes)]
-        fx = FrameExchange(W, H, payload="nu", device=dev, render_lanes=2)   # gloo -> strips bounce through pinned host memory
-        assert fx.stage
+        fx = FrameExchange(W, H, payload="nu", device=dev, render_lanes=2, layout=layout)   # gloo -> shares bounce through pinned host memory
+        assert fx.stage and fx.bands == (layout == "bands")
 
         def render_fn(shard, out, frame, plane, lane=0):
             (r, r2)[lane].render(states[frame], W, H, shard=shard, sync=False, nu=out,
@@ -751,16 +751,18 @@ def _fx_gpu_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_frame_exchange_two_ranks_sharing_the_card(fr):
-    """Rehearsal of the N > 1 GPU path on ONE card: 2 processes, gloo rendezvous, strips bounced through
+@pytest.mark.parametrize("layout", ["strips", "bands"])
+def test_frame_exchange_two_ranks_sharing_the_card(fr, layout):
+    """Rehearsal of the N > 1 GPU path on ONE card: 2 processes, gloo rendezvous, shares bounced through
     pinned host memory (RCCL refuses two ranks on one device).  Every frame delivered to rank
-    (frame mod 2) must equal, bitwise, a whole-frame render of the same state."""
+    (frame mod 2) must equal, bitwise, a whole-frame render of the same state.  Both layouts: interleaved row strips,
+    and contiguous bands that rotate over the frames of a group and are received in place."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_fx_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_fx_gpu_worker, args=(r, 2, port, q, layout)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=1024)
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to fr_ctx_set_option on every context")
     ap.add_argument("--only", type=int, default=0, help="only this N")
+    ap.add_argument("--bands", action="store_true", help="rotating bands: the N renders of a group are the N bands of H/N rows")
     args = ap.parse_args()
     import torch
     import fractalrenderer_amd as fr
@@ -49,16 +50,17 @@ def main():
     base = timed(lambda: rs[0].render(st, W, H, rgba=full, sync=False, stream=cur.cuda_stream))
     print("1 GPU whole frame rgba: %.3f ms" % base)
     for N in ((args.only,) if args.only else (1, 2, 4, 8)):
-        R = pick_rows_per_strip(H, N)
+        R = H // N if args.bands else pick_rows_per_strip(H, N)
         sh = fr.Shard(0, N, R)
         rows = sh.rows(H)
+        shard_of = (lambda j: fr.Shard(j, N, R)) if args.bands else (lambda j: sh)
         for plane in ("nu", "rgba"):
             bufs = [torch.empty((rows, W) + ((4,) if plane == "rgba" else ()),
                                 dtype=torch.float32 if plane == "rgba" else torch.float64, device=dev) for _ in range(N)]
 
             def seq():
                 for j in range(N):
-                    rs[0].render(st, W, H, shard=sh, sync=False, stream=cur.cuda_stream, **{plane: bufs[j]})
+                    rs[0].render(st, W, H, shard=shard_of(j), sync=False, stream=cur.cuda_stream, **{plane: bufs[j]})
 
             def multi(k):
                 def fn():
@@ -67,7 +69,7 @@ def main():
                         s = streams[j % k]
                         if j < k:
                             s.wait_stream(cur)
-                        rs[j % k].render(st, W, H, shard=sh, sync=False, stream=s.cuda_stream, **{plane: bufs[j]})
+                        rs[j % k].render(st, W, H, shard=shard_of(j), sync=False, stream=s.cuda_stream, **{plane: bufs[j]})
                     for s in streams[:k]:
                         cur.wait_stream(s)
                 return fn
