@@ -727,7 +727,7 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
  * used when orbit_trap / stripes / interior_style 2 need z itself or min_trap. */
 template <typename T>
 __device__ __forceinline__ void escape_run_effects(T& zx, T& zy, const T cx, const T cy, const T B2,
-                                                   const int max_iter, const uint64_t done_in,
+                                                   const int max_iter, const uint64_t done_in, const bool need_trap,
                                                    int& esc_i, T& esc_zx, T& esc_zy, T& min_trap)
 {
     /* The shader takes, every iteration, the minimum of length(z), min(|z.x|, |z.y|) and length(z - c) into minTrap
@@ -745,10 +745,12 @@ __device__ __forceinline__ void escape_run_effects(T& zx, T& zy, const T cx, con
         if (live) {
             zx = x; zy = y;
             const T r2 = zx * zx + zy * zy;
-            const T dx = zx - cx, dy = zy - cy;
-            m_origin2 = Real<T>::fmin(m_origin2, r2);
-            m_axes = Real<T>::fmin(m_axes, Real<T>::fmin(Real<T>::fabs(zx), Real<T>::fabs(zy)));
-            m_c2 = Real<T>::fmin(m_c2, dx * dx + dy * dy);
+            if (need_trap) {             /* wave-uniform: stripes alone need only the z of the escape */
+                const T dx = zx - cx, dy = zy - cy;
+                m_origin2 = Real<T>::fmin(m_origin2, r2);
+                m_axes = Real<T>::fmin(m_axes, Real<T>::fmin(Real<T>::fabs(zx), Real<T>::fabs(zy)));
+                m_c2 = Real<T>::fmin(m_c2, dx * dx + dy * dy);
+            }
             if (r2 > B2) { esc_i = i; live = false; }
         }
         done |= __builtin_amdgcn_ballot_w64(!live);
@@ -932,7 +934,8 @@ tile_kernel(const LaunchArgs A)
                     } else {
                         T zx = T(0), zy = T(0), ezx, ezy, min_trap;
                         escape_run_effects<T>(zx, zy, inside ? cx : T(0), inside ? cy : T(0), B2,
-                                              max_iter, outside_mask, it, ezx, ezy, min_trap);
+                                              max_iter, outside_mask, A.trap_enabled != 0 || A.interior_style == 2,
+                                              it, ezx, ezy, min_trap);
                         nu = (T)it;
                         if (it < max_iter) {
                             const T log_zn = Real<T>::log(ezx * ezx + ezy * ezy) / T(2);
