@@ -723,40 +723,84 @@ __device__ __forceinline__ void escape_run(Orbit<T>& o, const T B2, const int i0
     }
 }
 
-/* As-written form with the reference's 3-way orbit trap (shaders/mandelbrot.comp:157-170):
- * used when orbit_trap / stripes / interior_style 2 need z itself or min_trap. */
+/* The reference's loop with its 3-way orbit trap (shaders/mandelbrot.comp:157-170), for the colourings that need
+ * minTrap or the z of the escape (orbit trap, stripes, interior style 2).
+ *
+ * Every iteration the shader takes min(length(z), min(|z.x|, |z.y|), length(z - c)) into minTrap.  A correctly
+ * rounded square root is monotonic, so min_i sqrt(a_i) == sqrt(min_i a_i) bit for bit: the loop keeps the minima of
+ * the SQUARED lengths and takes the two roots once, after it.  It runs in the scaled-imaginary form of escape_run
+ * (Yd = 2 Im z, exact power-of-two scalings; see there), so the minima are kept scaled too and scaled back at the end:
+ *     4 |z|^2     = fma(4, x2, y2d)                         (= 4 RN(zx^2 + zy^2), the dot() of length())
+ *     |z.y|       = |Yd| / 2
+ *     4 |z - c|^2 = fma(4, RN(dx^2), RN(dyd^2)),  dyd = Yd - cyd = 2 (zy - cy)   (= 4 RN(dx^2 + dy^2))
+ * and sqrt(m / 4) == sqrt(m) / 2 exactly.  Unchecked blocks as in escape_run: a block in which some running lane
+ * escaped is rolled back -- orbit AND minima -- and replayed with per-update tests, which stops every lane's minima
+ * at its escape.  A finished lane is parked at NaN: every later minimum with its values is a no-op (minNum ignores
+ * NaN) and it never tests as escaped; the dirty-block test looks at running lanes only. */
 template <typename T>
-__device__ __forceinline__ void escape_run_effects(T& zx, T& zy, const T cx, const T cy, const T B2,
-                                                   const int max_iter, const uint64_t done_in, const bool need_trap,
+__device__ __forceinline__ void escape_run_effects(Orbit<T>& o, const T B2, const int max_iter, const bool fast_ok,
+                                                   const bool lane_runs, const bool need_trap,
                                                    int& esc_i, T& esc_zx, T& esc_zy, T& min_trap)
 {
-    /* The shader takes, every iteration, the minimum of length(z), min(|z.x|, |z.y|) and length(z - c) into minTrap
-     * (shaders/mandelbrot.comp:163-166).  A correctly rounded square root is monotonic, so
-     * min_i sqrt(a_i) == sqrt(min_i a_i) bit for bit: the loop keeps the minima of the SQUARED lengths and takes the
-     * two square roots once, after it -- 2 x ~25 fp64 instructions less per iteration, same minTrap. */
     esc_i = max_iter;
-    T m_origin2 = (T)__builtin_inff(), m_axes = T(1e20), m_c2 = (T)__builtin_inff();
-    bool live = true;
-    uint64_t done = done_in;
-    for (int i = 0; i < max_iter; ++i) {
+    esc_zx = T(0); esc_zy = T(0);
+    const T B2x4 = T(4) * B2;
+    const T kInf = (T)__builtin_inff(), kNaN = (T)__builtin_nanf("");
+    T m_o4 = kInf, m_ax = T(1e20), m_ayd = T(2e20), m_c4 = kInf;
+    uint32_t fin = lane_runs ? 0u : 1u;                          /* VGPR flag, as in the lane pool */
+    if (!lane_runs) { o.X = kNaN; o.Yd = kNaN; o.x2 = kNaN; o.y2d = kNaN; }
+    uint64_t done = __builtin_amdgcn_ballot_w64(fin != 0u);
+    int i = 0;
+    bool fast = false;
+    auto accumulate = [&]() {
+        m_o4 = Real<T>::fmin(m_o4, orbit_r2x4(o));
+        m_ax = Real<T>::fmin(m_ax, Real<T>::fabs(o.X));
+        m_ayd = Real<T>::fmin(m_ayd, Real<T>::fabs(o.Yd));
+        const T dx = o.X - o.cx, dyd = o.Yd - o.cyd;
+        m_c4 = Real<T>::fmin(m_c4, Real<T>::fma(T(4), dx * dx, dyd * dyd));
+    };
+    while (i < max_iter) {
         if (done == ~0ull) break;
-        const T x = zx * zx - zy * zy + cx;
-        const T y = T(2) * zx * zy + cy;
-        if (live) {
-            zx = x; zy = y;
-            const T r2 = zx * zx + zy * zy;
-            if (need_trap) {             /* wave-uniform: stripes alone need only the z of the escape */
-                const T dx = zx - cx, dy = zy - cy;
-                m_origin2 = Real<T>::fmin(m_origin2, r2);
-                m_axes = Real<T>::fmin(m_axes, Real<T>::fmin(Real<T>::fabs(zx), Real<T>::fabs(zy)));
-                m_c2 = Real<T>::fmin(m_c2, dx * dx + dy * dy);
+        const int left = max_iter - i;
+        if (fast && left >= kFastBlock) {
+            const Orbit<T> snap = o;
+            const T s_o4 = m_o4, s_ax = m_ax, s_ayd = m_ayd, s_c4 = m_c4;
+            /* not fully unrolled: with its four running minima a 16-update straight line costs the kernel 157 VGPRs
+             * (3 waves per SIMD); two updates per trip keep it at the tile kernel's usual budget */
+            if (need_trap) {
+#pragma unroll 2
+                for (int k = 0; k < kFastBlock; ++k) { orbit_step<T, false>(o); accumulate(); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kFastBlock; ++k) orbit_step<T, false>(o);
             }
-            if (r2 > B2) { esc_i = i; live = false; }
+            const bool bad = fin == 0u && !(orbit_r2x4(o) <= B2x4);
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) { i += kFastBlock; continue; }
+            o = snap; m_o4 = s_o4; m_ax = s_ax; m_ayd = s_ayd; m_c4 = s_c4;
+            fast = false;
         }
-        done |= __builtin_amdgcn_ballot_w64(!live);
+        const int end = i + (left < kFastBlock ? left : kFastBlock);
+        const uint64_t before = done;
+        for (; i < end; ++i) {
+            orbit_step<T, false>(o);
+            if (need_trap) accumulate();                         /* the escaping z is part of the minima, as written */
+            const bool e = orbit_r2x4(o) > B2x4;
+            const uint64_t em = __builtin_amdgcn_ballot_w64(e);
+            if (em != 0ull) {
+                if (e) {
+                    esc_i = i; esc_zx = o.X; esc_zy = T(0.5) * o.Yd; fin = 1u;
+                    o.X = kNaN; o.Yd = kNaN; o.x2 = kNaN; o.y2d = kNaN;
+                }
+                done |= em;
+                if (done == ~0ull) { ++i; break; }
+            }
+        }
+        if (done == ~0ull) break;
+        fast = fast_ok && done == before;
     }
-    min_trap = Real<T>::fmin(T(1e20), Real<T>::fmin(Real<T>::sqrt(m_origin2), Real<T>::fmin(m_axes, Real<T>::sqrt(m_c2))));
-    esc_zx = zx; esc_zy = zy;
+    if (fin == 0u) { esc_zx = o.X; esc_zy = T(0.5) * o.Yd; }      /* never escaped: the z after max_iter updates */
+    const T m_axes = Real<T>::fmin(m_ax, T(0.5) * m_ayd);
+    min_trap = Real<T>::fmin(T(1e20), Real<T>::fmin(T(0.5) * Real<T>::sqrt(m_o4), Real<T>::fmin(m_axes, T(0.5) * Real<T>::sqrt(m_c4))));
 }
 
 /* As-written Burning Ship loop with its trap / stripe accumulators (shaders/burning_ship.comp:228-256):
@@ -932,10 +976,12 @@ tile_kernel(const LaunchArgs A)
                         }
                         if (!alive) shade<T, 0>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
                     } else {
-                        T zx = T(0), zy = T(0), ezx, ezy, min_trap;
-                        escape_run_effects<T>(zx, zy, inside ? cx : T(0), inside ? cy : T(0), B2,
-                                              max_iter, outside_mask, A.trap_enabled != 0 || A.interior_style == 2,
-                                              it, ezx, ezy, min_trap);
+                        T ezx, ezy, min_trap;
+                        Orbit<T> o;
+                        o.X = T(0); o.Yd = T(0); o.x2 = T(0); o.y2d = T(0);
+                        o.cx = cx; o.cyd = T(2) * cy;
+                        escape_run_effects<T>(o, B2, max_iter, A.fast_ok != 0, inside,
+                                              A.trap_enabled != 0 || A.interior_style == 2, it, ezx, ezy, min_trap);
                         nu = (T)it;
                         if (it < max_iter) {
                             const T log_zn = Real<T>::log(ezx * ezx + ezy * ezy) / T(2);
