@@ -28,6 +28,12 @@ for trial in range(trials):
               interior_style=int(rng.choice([0, 0, 1])), post_chain=int(rng.integers(0, 2)), aa=int(rng.choice([1, 1, 1, 2])))
     if fractal == 1:
         kw.update(julia_c_real=float(rng.uniform(-0.9, 0.4)), julia_c_imag=float(rng.uniform(-0.7, 0.7)))
+    if prec == 1 and fractal in (0, 2) and rng.random() < 0.3:
+        # the effects variants (orbit trap, stripes, interior styles): fp64 only -- in fp32 the stripe angle inherits
+        # the escape z's last bits
+        kw.update(orbit_trap_enabled=int(rng.integers(0, 2)), stripe_enabled=int(rng.integers(0, 2)),
+                  interior_style=int(rng.choice([0, 1, 2, 3])), orbit_trap_radius=float(np.float32(rng.uniform(0.1, 1.5))),
+                  stripe_density=float(np.float32(rng.uniform(1.0, 20.0))))
     if prec == 0:
         kw["aa"] = 1          # fp32 samples next to the palette's fract() wrap legitimately flip; only checkable per pixel
     p = oracle.OracleParams(**kw)
