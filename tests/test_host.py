@@ -521,6 +521,8 @@ def test_hot_kernels_keep_their_register_budget(fr):
         "_ZN2fr11pool_kernelIfLi1ELi3ELb1ELb0EEEvNS_10LaunchArgsE": (64, 6, 8),    # fp32 Julia lane pool (C3)
         "_ZN2fr11tile_kernelIdLi0ELi3ELb0ELb0ELb0EEEvNS_10LaunchArgsE": (96, 5, 48),   # fp64 Mandelbrot tile pass
         "_ZN2fr11tile_kernelIfLi1ELi3ELb0ELb0ELb0EEEvNS_10LaunchArgsE": (64, 5, 24),   # fp32 Julia tile pass
+        # the effects variant (orbit trap / stripes): its fp64 atan2 + sin epilogue holds it at 3 waves per SIMD
+        "_ZN2fr11tile_kernelIdLi0ELi3ELb1ELb0ELb0EEEvNS_10LaunchArgsE": (168, 3, 16),
     }
     for name, (max_vgpr, min_occ, max_spill) in budget.items():
         u = usage.get(name)
