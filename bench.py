@@ -132,6 +132,19 @@ def pmc_traffic(workload_name: str):
         return None
 
 
+def pmc_valu_busy(workload_name: str):
+    """VALU busy of the frame's kernels from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json):
+    SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8); None for workloads that were not profiled."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        e = json.load(open(path)).get(workload_name) or {}
+        vb = e.get("valu_busy")
+        return {"frame": round(vb["frame"], 4), "per_kernel": {k: round(v, 4) for k, v in vb["per_kernel"].items()},
+                "sustained_clock_ghz": round(vb["clock_ghz"], 3), "source": e.get("source")} if vb else None
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,6 +384,7 @@ def main() -> None:
                                     "issue_note": "the kernels issue 6 VALU instructions per update (two are FMAs by exact powers of "
                                                   "two standing for two as-written operations each): frac prices the 8 as-written "
                                                   "flops and can exceed 1, issue_frac prices the 6 instructions",
+                                    "valu_busy_pmc": pmc_valu_busy(args.workload),
                                     "executed_iterations": executed,
                                     "mean_iterations_per_pixel": round(executed / (W * H), 2)}
             if dt_cyc is not None:

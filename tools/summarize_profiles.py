@@ -48,6 +48,15 @@ t = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
 t[workload] = {"hbm_bytes_per_launch": int(round((w + 2.0 * f) * 1024)), "WRITE_SIZE_KiB": w, "FETCH_SIZE_KiB_raw": f,
                "source": f"profiles/{tag}_pmc.json",
                "note": "per frame = tile pass + lane-pool pass; WRITE_SIZE + 2*FETCH_SIZE (gfx950 FETCH_SIZE counts half), KiB -> bytes"}
+# VALU busy from the PMC passes, per kernel and per frame: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the waves,
+# GRBM_GUI_ACTIVE counts cycles summed over the 8 XCDs; 1024 SIMDs (256 CUs x 4)
+def busy(active_valu, gui):
+    return active_valu * 4.0 / (1024.0 * gui / 8.0) if gui else None
+vb = {kn: busy(v["SQ_ACTIVE_INST_VALU"]["mean"], v["GRBM_GUI_ACTIVE"]["mean"]) for kn, v in pmc.items()
+      if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v}
+t[workload]["valu_busy"] = {"frame": busy(frame.get("SQ_ACTIVE_INST_VALU", 0.0), frame.get("GRBM_GUI_ACTIVE", 0.0)),
+                            "per_kernel": vb, "clock_ghz": frame.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / (out["kernel_trace_frame_ms"] * 1e6) if out["kernel_trace_frame_ms"] else None,
+                            "note": "SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)"}
 json.dump(t, open(traffic_path, "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read()[:500])
 print("frame ms (sum of kernel averages):", out["kernel_trace_frame_ms"])
