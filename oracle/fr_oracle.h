@@ -13,7 +13,7 @@
  * one invocation per pixel, through the SPIR-V interpreter
  * tests/golden/spirv_interp.py (ours; IEEE binary32, one rounding per
  * instruction) and commits what they write as tests/golden/spv_frames.npz
- * (67 cases over mandelbrot / julia / burning_ship / test_deep_zoom);
+ * (70 cases over mandelbrot / julia / burning_ship / test_deep_zoom);
  * tests/test_spv_golden.py requires this restatement to reproduce them --
  * escape indices bit-exact, written texels within 5e-6.  The fp64 variants
  * have no counterpart in the reference (it has no fp64 shader): they are the

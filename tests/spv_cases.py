@@ -44,6 +44,10 @@ _add("m_interior5_fallback", "mandelbrot", 16, 12, max_iterations=48, interior_s
 _add("m_aa4_offset", "mandelbrot", 6, 4, max_iterations=40, aa=4, color_offset=0.6, color_scale=3.0, palette_mode=3)
 _add("m_wide_frame", "mandelbrot", 40, 6, center_x=-0.75, center_y=0.1, zoom=1.2, max_iterations=200, palette_mode=4)
 
+# long orbits next to the boundary: 2000 chaotic updates amplify any difference in operation order or rounding
+_add("m_long_orbits", "mandelbrot", 12, 8, center_x=SEAHORSE[0], center_y=SEAHORSE[1], zoom=0.0004, max_iterations=2000,
+     palette_mode=1, color_scale=3.0)
+
 # ---- shaders/julia.comp.spv --------------------------------------------------------------------------------
 _add("j_default", "julia", 64, 48, center_x=0.0, max_iterations=256)
 for _m in range(10):
@@ -57,6 +61,9 @@ _add("j_bailout8", "julia", 16, 12, center_x=0.1, center_y=-0.2, zoom=1.5, max_i
 _add("j_palette12_fallback", "julia", 16, 12, center_x=0.0, max_iterations=64, palette_mode=12, color_offset=0.15, color_scale=1.3)
 _add("j_aa3", "julia", 8, 6, center_x=0.0, max_iterations=64, aa=3, julia_c_real=0.285, julia_c_imag=0.01, palette_mode=2)
 _add("j_tall_frame", "julia", 7, 33, center_x=0.0, zoom=2.8, max_iterations=150, julia_c_real=-0.4, julia_c_imag=0.6, palette_mode=5)
+
+_add("j_long_orbits", "julia", 12, 8, center_x=1.2, center_y=0.0, zoom=0.01, max_iterations=2000,
+     julia_c_real=-0.8, julia_c_imag=0.156, palette_mode=3)
 
 # ---- shaders/burning_ship.comp.spv -------------------------------------------------------------------------
 _add("s_default", "burning_ship", 64, 48, center_x=-0.5, center_y=-0.5, max_iterations=256)
@@ -77,6 +84,9 @@ _add("s_aa2_post", "burning_ship", 12, 8, center_x=-0.5, center_y=-0.5, max_iter
 _add("s_palette11_fallback", "burning_ship", 16, 12, center_x=-0.5, center_y=-0.5, max_iterations=64, palette_mode=11)
 _add("s_bailout8", "burning_ship", 18, 12, center_x=-1.755, center_y=-0.03, zoom=0.3, max_iterations=100, bailout=8.0, palette_mode=6)
 _add("s_aa3_trap", "burning_ship", 8, 6, center_x=-0.5, center_y=-0.5, max_iterations=48, aa=3, orbit_trap_enabled=1, orbit_trap_radius=0.4)
+
+_add("s_long_orbits", "burning_ship", 12, 8, center_x=-1.7720666666666665, center_y=-0.017733333333333334, zoom=0.0006, max_iterations=2000,
+     palette_mode=7)
 
 # ---- shaders/test_deep_zoom.comp.spv (FractalType::Deep_Zoom) ----------------------------------------------
 _add("d_seahorse", "test_deep_zoom", 18, 10, center_x=SEAHORSE[0], center_y=SEAHORSE[1], zoom=1e-6, max_iterations=1200,

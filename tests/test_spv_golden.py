@@ -76,6 +76,8 @@ def test_fp64_restatement_is_the_same_algorithm_at_wider_precision(oracle, spv):
     for name, (shader, p, W, H) in SPV_CASES.items():
         if shader == "test_deep_zoom" or p.aa != 1:         # Deep_Zoom has no fp64 variant in the reference
             continue
+        if name.endswith("_long_orbits"):                   # chaos on purpose: fp32 and fp64 part ways there by design
+            continue
         f = oracle.render(dataclasses.replace(p, precision=1), W, H)
         same = f.iter == spv[name + "/iter"]
         assert same.mean() >= 0.85, name
