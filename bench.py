@@ -14,6 +14,17 @@ The ranks ship the 8-byte smooth-count plane and the destination recolours it (b
 direct render), so every frame ends complete -- RGBA f32 + nu -- in the HBM of one GPU, as at N = 1.
 Strong scaling: the same K frames whatever N.
 
+Launching.  The driver starts N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(WORLD_SIZE set: this process IS a rank).  From a bare shell `python bench.py --gpus N` works too: with WORLD_SIZE
+unset and N > 1 the process becomes a LAUNCHER -- before torch is imported or anything touches the GPU it starts
+`python -m torch.distributed.run` as a child process (never an exec), relays rank 0's JSON line and exits with the
+child's status.
+
+--mode sequence (default) times K frames in rotating-root groups as above; --mode frame times the north-star's literal
+case at N > 1: ONE frame tiled over the N GPUs as row strips with a final gather to rank 0 (StripGather: grouped RCCL
+send/recv into the root, double-buffered so that gather(n) overlaps render(n+1)); at N = 1 both modes are the same
+whole-frame render.
+
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline       the metric's own roofline ("achieved HBM GB/s vs peak"): algorithmic bytes
                  16 B/pixel (RGBA f32, write-once) / average kernel time measured with HIP events
@@ -99,6 +110,15 @@ def cpu_baseline(workload: dict) -> dict:
             O.render(p, W, H, y0=y0, y1=y0 + band_rows, threads=threads, planes=False)
             px += band_rows * W
     dt = time.perf_counter() - t0
+    # SURVEY.md section 8d also asks for the single-thread figure: one pass over narrower bands of the same frame
+    rows1 = max(1, band_rows // 4)
+    t1s = time.perf_counter()
+    px1 = 0
+    for b in range(bands):
+        y0 = (H // bands) * b + (H // bands - rows1) // 2
+        O.render(p, W, H, y0=y0, y1=y0 + rows1, threads=1, planes=False)
+        px1 += rows1 * W
+    dt1 = time.perf_counter() - t1s
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -115,6 +135,8 @@ def cpu_baseline(workload: dict) -> dict:
     got = O.lib().fro_reference_orbit(-0.5, 0.0, n_orbit, buf.ctypes.data)
     orbit_rate = got / (time.perf_counter() - t1)
     return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": round(px1 / dt1 / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
+                              "sample": f"1 pass over {bands} evenly spaced bands of {rows1} rows ({px1} pixels), {dt1:.1f} s"},
             "reference_orbit_iterations_per_s": round(orbit_rate, 0),
             "sample": f"{passes} passes over {bands} evenly spaced bands of {band_rows} rows ({px // passes} of {W*H} pixels) of the same frame, "
                       f"oracle/fr_oracle.c -O2 -ffp-contract=off, OpenMP schedule(dynamic,1), {dt:.1f} s",
@@ -145,12 +167,15 @@ def pmc_valu_busy(workload_name: str):
         return None
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="sequence", choices=["sequence", "frame"],
+                    help="N > 1: 'sequence' = K frames in rotating-root groups (FrameExchange); 'frame' = the north-star's "
+                         "literal case, every frame tiled over the N GPUs as row strips and gathered to rank 0 (StripGather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelined", action="store_true",
                     help="N = 1: after the timed region, also time the same K steps with two frames in flight "
@@ -171,20 +196,134 @@ def main() -> None:
                     help="N > 1: concurrent render contexts/streams per rank (0: min(4, N))")
     ap.add_argument("--dist-backend", default="nccl", help="rehearsals only: gloo + --same-device on one card")
     ap.add_argument("--same-device", action="store_true", help="rehearsals only: every rank uses cuda:0")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-rehearsal", action="store_true",
+                    help="N > 1, no GPU: gloo ranks run the launcher, the rendezvous and the exchange of --mode on CPU tensors "
+                         "filled with a stand-in pattern instead of rendered planes (tests/test_dist_cpu.py drives the "
+                         "launcher path with it); the printed value is NOT a measurement")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` from a bare shell (WORLD_SIZE unset, N > 1): start the N ranks as CHILD processes through
+    torch.distributed.run -- before this process has imported torch or touched the GPU, and without exec (a process that
+    has initialised the GPU must never be replaced) -- relay rank 0's JSON line, return the children's status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL peer mappings need it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:                                 # stderr goes straight through; stdout is scanned for THE line
+        t = out.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py launcher: the ranks exited cleanly but rank 0 printed no JSON line\n")
+        rc = 1
+    return rc
+
+
+def cpu_rehearsal(args) -> None:
+    """The N > 1 control flow of --mode without a GPU: gloo rendezvous, the exchange on CPU tensors whose 'rendered' planes
+    are a stand-in pattern (frame * 65536 + global row), every delivered frame verified; rank 0 prints a JSON line shaped
+    like the real one.  Exercised by tests/test_dist_cpu.py through the launcher; never a measurement."""
+    import torch
+    import torch.distributed as dist
+    from fractalrenderer_amd.distributed import FrameExchange, StripGather
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("FR_BENCH_REHEARSAL_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                                  # the launcher must hand a rank's failure on
+    dist.init_process_group("gloo")
+    W, H = 64, 48
+    cpu = torch.device("cpu")
+    pattern = lambda frame, rows: (frame * 65536.0 + torch.from_numpy(rows).double())[:, None].expand(len(rows), W)  # noqa: E731
+    whole = lambda frame: pattern(frame, __import__("numpy").arange(H))  # noqa: E731
+    ok = True
+    t0 = time.perf_counter()
+    if args.mode == "frame":
+        sg = StripGather(W, H, 1, torch.float64, cpu, rows_per_strip=args.rows_per_strip)
+
+        def render_fn(shard, out, frame):
+            out.copy_(pattern(frame, shard.global_rows(H)).unsqueeze(-1))
+
+        for f in range(args.warmup + args.steps):
+            slot = sg.submit(render_fn, f)
+            sg.drain()
+            if rank == 0:
+                ok = ok and bool(torch.equal(sg.frames[slot][..., 0], whole(f)))
+        desc = f"StripGather to rank 0, strips of {sg.R} rows"
+    else:
+        fx = FrameExchange(W, H, payload="nu", nu_dtype=torch.float64, device=cpu, rows_per_strip=args.rows_per_strip,
+                           layout=args.layout)
+
+        def render_fn(shard, out, frame, plane, lane=0):
+            out.copy_(pattern(frame, shard.global_rows(H)))
+
+        def colorize_fn(nu_frame, rgba_frame, frame):
+            rgba_frame.copy_(nu_frame.float().unsqueeze(-1).expand(H, W, 4))
+
+        fx.prime()
+        f = 0
+        while f < args.warmup + args.steps:
+            count = min(world, args.warmup + args.steps - f)
+            slot = fx.submit_group(render_fn, f, count, colorize_fn)
+            fx.drain()
+            if rank < count:
+                ok = ok and bool(torch.equal(fx.frame_nu[slot], whole(f + rank)))
+            f += count
+        desc = f"FrameExchange, {'bands' if fx.bands else 'strips'} of {fx.R} rows"
+    dt = time.perf_counter() - t0
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        n = args.warmup + args.steps
+        print(json.dumps({"metric": "rehearsal (no GPU): launcher + rendezvous + exchange on CPU tensors; not a measurement",
+                          "value": round(n * W * H / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(dt / n * 1e3, 4), "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "stand-in pattern",
+                          "rehearsal": "cpu", "exchange_verified": bool(flag.item()),
+                          "config": {"workload": f"{W}x{H} stand-in planes", "mode": args.mode, "parallelism": desc}}), flush=True)
+    dist.destroy_process_group()
+    if not flag.item():
+        raise SystemExit(4)
+
+
+def main() -> None:
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    # before torch is imported and before any HIP call: dmabuf IPC for RCCL's peer mappings (read at runtime init)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, argv))
+    if args.cpu_rehearsal:
+        if args.gpus < 2:
+            raise SystemExit("--cpu-rehearsal rehearses the N > 1 path: use --gpus 2 or more")
+        cpu_rehearsal(args)
+        return
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import fractalrenderer_amd as fr
-    from fractalrenderer_amd.distributed import FrameExchange
+    from fractalrenderer_amd.distributed import FrameExchange, StripGather
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if args.same_device:
@@ -192,7 +331,6 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -292,6 +430,57 @@ def main() -> None:
             dt_pipe = time.perf_counter() - t0p
             r2.close()
             del rgba2
+    elif args.mode == "frame":
+        # The north-star's literal case: ONE frame tiled over the N GPUs, gathered to rank 0.  Interleaved row strips
+        # (contiguous H/N bands would leave the ranks that hold the set with several times the work), one render per
+        # rank and frame, one grouped batch of RCCL send/recv into the root (N-1 concurrent xGMI transfers),
+        # double-buffered: gather(n) overlaps render(n+1).  Payload nu (8 / 4 B per pixel, recoloured on the root,
+        # bit-identical) where the colour is a function of nu, else the 16-byte colour plane.
+        payload = args.payload
+        if payload == "auto":
+            payload = "nu" if r.colorize_supported(state, ftype, prec) else "rgba"
+        nu_dtype = torch.float64 if prec == fr.Precision.F64 else torch.float32
+        lanes = 1
+        ctxs = [r]
+        fx = sg = StripGather(W, H, 4 if payload == "rgba" else 1, torch.float32 if payload == "rgba" else nu_dtype, dev,
+                              rows_per_strip=args.rows_per_strip)
+        root_rgba = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(sg.nbuf)] \
+            if (rank == 0 and payload == "nu") else []
+
+        def render_fn(shard, out, _frame):
+            kw = {"nu": out} if payload == "nu" else {"rgba": out}
+            r.render(state, W, H, fractal_type=ftype, precision=prec, shard=shard, sync=False,
+                     stream=torch.cuda.current_stream().cuda_stream, **kw)
+
+        def run(nframes):
+            for f in range(nframes):
+                slot = sg.submit(render_fn, f)
+                if rank == 0 and payload == "nu":                # recolour the assembled frame behind its gather
+                    with torch.cuda.stream(sg.comm):
+                        r.colorize(state, sg.frames[slot][..., 0], root_rgba[slot], fractal_type=ftype, precision=prec,
+                                   stream=torch.cuda.current_stream().cuda_stream)
+                        sg.gathered[slot].record(sg.comm)
+            sg.drain()
+
+        run(max(1, args.warmup))                                 # also opens the peer connections
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        last_ms = r.last_kernel_ms()
+        lane_ms = [last_ms]
+        run(1)                                                   # outside the timed region: verify the gathered frame
+        okv = 1
+        if rank == 0:
+            direct = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+            r.render(state, W, H, fractal_type=ftype, precision=prec, rgba=direct)
+            got = root_rgba[0] if payload == "nu" else sg.frames[0]
+            okv = 1 if torch.equal(got, direct) else 0
+            del direct
+        ok = torch.tensor([okv], dtype=torch.int32, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        exchange_verified = bool(ok.item())
     else:
         payload = args.payload
         if payload == "auto":
@@ -358,14 +547,19 @@ def main() -> None:
             "scaling": "strong",
             "vs_baseline": None, "dtype": "f64" if prec == fr.Precision.F64 else "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "output": "RGBA f32 linear colour, 16 B/pixel, resident in HBM",
-                       "parallelism": ((f"disjoint row bands of {fx.R} rows, one per GPU and frame, the band of a GPU rotating over "
+                       "parallelism": "1 GPU, persistent tile queue" if world == 1 else
+                                      (f"mode frame: every frame tiled over {world} GPUs as row strips of {fx.R} rows dealt round-robin, "
+                                       f"gathered to rank 0 by one grouped RCCL send/recv batch per frame (payload: {payload} plane"
+                                       f"{', recoloured on the root' if payload == 'nu' else ''}; double-buffered: gather(n) overlaps "
+                                       f"render(n+1))" if args.mode == "frame" else
+                                       (f"disjoint row bands of {fx.R} rows, one per GPU and frame, the band of a GPU rotating over "
                                         f"the frames of a group; " if fx.bands else
                                         f"row strips of {fx.R} rows round-robin over {world} GPUs; ") +
                                        f"frames in groups of {world}, "
                                        f"frame g*{world}+j gathered to rank j by one RCCL all-to-all per group "
                                        f"(payload: {payload} plane, {'recoloured at the destination, ' if payload == 'nu' else ''}"
-                                       f"double-buffered, {lanes} concurrent render contexts per rank)" if world > 1
-                                       else "1 GPU, persistent tile queue"),
+                                       f"double-buffered, {lanes} concurrent render contexts per rank)"),
+                       "mode": args.mode if world > 1 else "frame",
                        "compute_units": r.compute_units},
         }
         if world == 1:

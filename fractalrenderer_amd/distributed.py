@@ -74,6 +74,13 @@ class StripGather:
                                   for r in range(self.world)])
         self._rows_of = [Shard(r, self.world, self.R).global_rows(height) for r in range(self.world)] \
             if self.rank == root else []
+        # gloo cannot move device tensors point-to-point: rehearsals of the GPU path on one card bounce the shares
+        # through pinned host memory (RCCL moves device memory directly)
+        self.stage = self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "gloo"
+        if self.stage:
+            pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)  # noqa: E731
+            self._hsend = pin(self.shard_buf[0])
+            self._hrecv = [pin(t) for t in self.recv[0]] if self.rank == root else []
         if self.on_gpu:
             self.compute = torch.cuda.Stream(device=self.device)
             self.comm = torch.cuda.Stream(device=self.device)
@@ -104,16 +111,25 @@ class StripGather:
             # differ per rank (ragged last strip), so each rank sends exactly its own bytes and the
             # root posts one receive per peer, all batched into one group (7 concurrent xGMI
             # point-to-point transfers into the root at world 8)
+            src = self.shard_buf[b]
+            dst = self.recv[b] if self.rank == self.root else []
+            if self.stage:
+                self._hsend.copy_(src)
+                torch.cuda.current_stream().synchronize()
+                src, dst = self._hsend, self._hrecv
             if self.rank == self.root:
                 self.recv[b][self.root].copy_(self.shard_buf[b])
-                ops = [dist.P2POp(dist.irecv, self.recv[b][r], r, self.group)
-                       for r in range(self.world) if r != self.root and self.recv[b][r].numel()]
+                ops = [dist.P2POp(dist.irecv, dst[r], r, self.group)
+                       for r in range(self.world) if r != self.root and dst[r].numel()]
             else:
-                ops = [dist.P2POp(dist.isend, self.shard_buf[b], self.root, self.group)] \
-                    if self.shard_buf[b].numel() else []
+                ops = [dist.P2POp(dist.isend, src, self.root, self.group)] if src.numel() else []
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()          # NCCL: makes the current stream wait; gloo: blocks the host
+            if self.stage and self.rank == self.root:
+                for r in range(self.world):
+                    if r != self.root:
+                        self.recv[b][r].copy_(dst[r], non_blocking=True)
         if self.rank == self.root:
             self._assemble(b)
 

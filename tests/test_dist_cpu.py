@@ -145,3 +145,51 @@ def test_frame_exchange_gloo(oracle, fr, world, W, H, R, payload, nframes, layou
         assert ok, rank
         seen += got
     assert sorted(seen) == list(range(nframes))          # every frame was delivered exactly once
+
+
+def _bench(*flags, env_extra=None, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.parametrize("mode,extra", [("sequence", ["--layout", "bands"]), ("sequence", ["--layout", "strips", "--rows-per-strip", "4"]),
+                                        ("frame", [])])
+def test_bench_launches_its_own_ranks(fr, mode, extra):
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): the process must become a launcher -- start the two
+    ranks as child processes through torch.distributed.run, relay rank 0's ONE JSON line on stdout, exit 0.  Driven with
+    --cpu-rehearsal (gloo, CPU tensors, stand-in planes): the launcher, the rendezvous and the exchange code are the
+    real ones, no GPU is touched."""
+    import json
+    out = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--mode", mode, "--cpu-rehearsal", *extra)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["rehearsal"] == "cpu"
+    assert d["exchange_verified"] is True and d["config"]["mode"] == mode
+
+
+def test_bench_launcher_hands_on_a_failing_rank(fr):
+    """A rank that dies must fail the launcher (non-zero status, no JSON line), not hang it or be swallowed."""
+    out = _bench("--gpus", "2", "--steps", "2", "--warmup", "0", "--cpu-rehearsal", env_extra={"FR_BENCH_REHEARSAL_FAIL_RANK": "1"})
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launcher_does_not_touch_torch_or_the_gpu_before_spawning():
+    """The launcher branch must run before `import torch` (a process that has initialised the GPU may not be replaced
+    or forked into ranks): statically, no torch import precedes launch_ranks() in main(), and HSA_ENABLE_IPC_MODE_LEGACY
+    is set before it."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    top_imports = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    names = {a.name.split(".")[0] for n in top_imports if isinstance(n, ast.Import) for a in n.names} | \
+            {(n.module or "").split(".")[0] for n in top_imports if isinstance(n, ast.ImportFrom)}
+    assert "torch" not in names and "fractalrenderer_amd" not in names
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    seg = ast.get_source_segment(src, main)
+    assert seg.index("HSA_ENABLE_IPC_MODE_LEGACY") < seg.index("launch_ranks(") < seg.index("import torch")

@@ -56,7 +56,17 @@ def gpu_render(fr, renderer, p, W, H, shard=None, host=False):
     return rgba.cpu().numpy(), nu.cpu().numpy(), it.cpu().numpy()
 
 
+# pixels that passed only through a tolerance EXCEPTION of check_against (the fp32 palette wrap, the pre-gamma comparison
+# next to black), against pixels checked: per call the exceptions must stay below EXCEPTION_CAP of the frame, and
+# test_tolerance_exceptions_stay_rare (last test of this file) holds the session total to the same cap.
+EXCEPTION_CAP = 1e-3
+EXCEPTIONS = {"pixels": 0, "wrap": 0, "pre_gamma": 0, "worst_call": 0.0}
+
+
 def check_against(p, ref_iter, ref_nu, ref_rgba, rgba, nu, it):
+    """Holds one render to the bars in this file's header.  Returns the number of pixels that were accepted through a
+    tolerance exception (0 for nearly every frame); more than max(2, 0.1 %) of the frame's pixels is a failure, so a
+    frame whose colours are systematically off cannot hide behind the exceptions."""
     assert np.array_equal(it, ref_iter), "escape indices differ: %d pixels" % int((it != ref_iter).sum())
     nu = nu.astype(np.float64)
     if p.precision == 1:
@@ -72,11 +82,13 @@ def check_against(p, ref_iter, ref_nu, ref_rgba, rgba, nu, it):
         # color_scale / max_iter (palette slope <= ~5): only visible for tiny max_iter (a soak case: max_iter = 1)
         tol += 5.0 * abs(p.color_scale) / p.max_iterations * 8e-6
     bad = d > tol
+    n_pre_gamma = n_wrap = 0
     if p.post_chain and bad.any():
         # the chain ends in pow(c, 1/2.2), whose slope is unbounded at 0: a 1e-7 difference of the linear colour next
         # to black (a palette knot evaluated as 0 on one side and 9e-8 on the other) comes out as 3e-4.  Such pixels
         # are compared before the gamma instead.
         lin = np.abs(np.power(rgba[..., :3].astype(np.float64), 2.2) - np.power(ref_rgba[..., :3].astype(np.float64), 2.2)).max(axis=-1)
+        n_pre_gamma = int((bad & ~(lin > 1e-6)).sum())
         bad &= lin > 1e-6
     if bad.any():
         assert p.precision == 0 and p.aa <= 1, "colour mismatch %g" % d.max()
@@ -90,6 +102,16 @@ def check_against(p, ref_iter, ref_nu, ref_rgba, rgba, nu, it):
         u = t - np.floor(t)
         near_wrap = np.minimum(u, 1 - u) < 1e-4
         assert np.all(near_wrap[bad]), "colour mismatch %g away from the palette wrap" % d[bad & ~near_wrap].max()
+        n_wrap = int(bad.sum())
+    n_exc = n_wrap + n_pre_gamma
+    npix = int(d.size)
+    EXCEPTIONS["pixels"] += npix
+    EXCEPTIONS["wrap"] += n_wrap
+    EXCEPTIONS["pre_gamma"] += n_pre_gamma
+    EXCEPTIONS["worst_call"] = max(EXCEPTIONS["worst_call"], n_exc / npix)
+    assert n_exc <= max(2, EXCEPTION_CAP * npix), \
+        "%d of %d pixels needed a tolerance exception (%d palette wrap, %d pre-gamma)" % (n_exc, npix, n_wrap, n_pre_gamma)
+    return n_exc
 
 
 @pytest.mark.parametrize("shape", [3, 4, 6])
@@ -554,6 +576,134 @@ def test_c5_franim_frames(fr, renderer, oracle, golden):
         check_against(p, ref.iter, ref.nu, ref.rgba, rgba[16:32], nu[16:32], it[16:32])
 
 
+def test_c1_full_size(fr, renderer, oracle):
+    """C1 (BASELINE.json configs[0]): Mandelbrot 512x512, max_iter 256, fp64, default viewport -- the whole frame
+    against the oracle, the workload table of BASELINE.md section 4, conjugate symmetry, and the host-buffer path."""
+    W = H = 512
+    p = oracle.OracleParams(max_iterations=256)
+    ref = oracle.render(p, W, H)
+    rgba, nu, it = gpu_render(fr, renderer, p, W, H)
+    assert renderer.last_stages() == 1                      # below the staging threshold: one pass
+    check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
+    assert np.array_equal(it[1:], it[1:][::-1]) and np.array_equal(nu[1:], nu[1:][::-1])
+    interior = float((it == 256).mean())
+    mean_it = float(np.where(it < 256, it.astype(np.int64) + 1, 256).mean())
+    assert abs(interior - 0.169) < 0.003 and abs(mean_it - 48.5) < 0.5, (interior, mean_it)
+    host = gpu_render(fr, renderer, p, W, H, host=True)
+    for a, b in zip((rgba, nu, it), host):
+        assert np.array_equal(a, b)
+    try:                                                    # the two-pass schedule on the same frame
+        renderer.set_option("staging", 3)
+        two = gpu_render(fr, renderer, p, W, H)
+        assert renderer.last_stages() == 2
+    finally:
+        renderer.set_option("staging", 0)
+    for a, b in zip((rgba, nu, it), two):
+        assert np.array_equal(a, b)
+
+
+def _band_check(oracle, p, W, H, planes, bands, rows=4):
+    """sampled full-width row bands of device planes (rgba, nu, it) against the oracle"""
+    rgba, nu, it = planes
+    for y0 in bands:
+        y1 = min(H, y0 + rows)
+        ref = oracle.render(p, W, H, y0=y0, y1=y1)
+        check_against(p, ref.iter, ref.nu, ref.rgba, rgba[y0:y1].cpu().numpy(), nu[y0:y1].cpu().numpy(), it[y0:y1].cpu().numpy())
+
+
+def test_c4_full_size(fr, renderer, oracle):
+    """C4 (BASELINE.json configs[3]) AS STATED: Mandelbrot 8192x8192, max_iter 16384, fp64, Seahorse deep preset at
+    zoom 1e-6.  Sampled full-width row bands against the oracle; interior fraction / mean iterations against
+    BASELINE.md section 4 (74.7 %, 12 553.6); every plane byte-identical under cycle closing on / off, the single
+    pass, and as 8 row bands and 8-way interleaved strips."""
+    import torch
+    W = H = 8192
+    p = oracle.OracleParams(center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-6, max_iterations=16384)
+    st = to_state(fr, p)
+    dev = torch.device("cuda:0")
+    mk = lambda rows: (torch.empty((rows, W, 4), dtype=torch.float32, device=dev),       # noqa: E731
+                       torch.empty((rows, W), dtype=torch.float64, device=dev),
+                       torch.empty((rows, W), dtype=torch.int32, device=dev))
+    base = mk(H)
+    try:
+        renderer.set_option("periodicity", 0)
+        renderer.render(st, W, H, rgba=base[0], nu=base[1], iter=base[2])
+        assert renderer.last_stages() == 2
+        t_plain = renderer.last_kernel_ms()
+        _band_check(oracle, p, W, H, base, (0, 2731, 4094, 8188))
+        it = base[2]
+        interior = float((it == 16384).double().mean())
+        mean_it = float(torch.where(it < 16384, it.to(torch.int64) + 1, torch.full_like(it, 16384, dtype=torch.int64)).double().mean())
+        assert abs(interior - 0.747) < 0.003 and abs(mean_it - 12555.0) < 30.0, (interior, mean_it)
+        other = mk(H)
+        for opts in (dict(periodicity=1), dict(staging=1)):
+            for k, v in opts.items():
+                renderer.set_option(k, v)
+            for t in other:
+                t.fill_(-3)
+            renderer.render(st, W, H, rgba=other[0], nu=other[1], iter=other[2])
+            for a, b in zip(base, other):
+                assert torch.equal(a, b), opts
+            if "periodicity" in opts:
+                assert renderer.last_kernel_ms() < 0.85 * t_plain        # the interior runs are cut short
+            for k in opts:
+                renderer.set_option(k, 0)
+        del other
+        renderer.set_option("periodicity", 1)                            # shards: with cycle closing (3x faster here)
+        for layout_R in (H // 8, 32):                                    # 8 contiguous row bands; interleaved strips of 32
+            for part in range(8):
+                sh = fr.Shard(part, 8, layout_R)
+                n = sh.rows(H)
+                got = mk(n)
+                renderer.render(st, W, H, rgba=got[0], nu=got[1], iter=got[2], shard=sh)
+                rows = torch.from_numpy(sh.global_rows(H)).to(dev)
+                for a, b in zip(base, got):
+                    assert torch.equal(a[rows], b), (layout_R, part)
+                del got
+    finally:
+        renderer.set_option("periodicity", 0)
+        renderer.set_option("staging", 0)
+
+
+def test_c5_full_size_row_bands(fr, renderer, oracle, golden):
+    """C5 (BASELINE.json configs[4]) AS STATED on one card: 8192x8192, max_iter 4096 (override), fp64, frames of the
+    reference's sample .franim at t = frame / target_fps, each rendered as the 8 disjoint row bands the 8 ranks would
+    render (rotating over the frame index as FrameExchange does), assembled, and compared -- bitwise with the
+    whole-frame render, and on sampled full-width row bands with the oracle.  The ranks' RCCL exchange itself is
+    covered by the gloo tests and the two-rank rehearsal; this is the arithmetic at the stated size."""
+    import torch
+    W = H = 8192
+    a = fr.AnimationSystem()
+    assert a.load_from_file(golden["franim"])
+    dev = torch.device("cuda:0")
+    for frame in (1234, 2399):
+        st = a.interpolate(a.frame_time(frame))
+        st.max_iterations = 4096
+        p = oracle.OracleParams(center_x=st.center_x, center_y=st.center_y, zoom=st.zoom, max_iterations=4096,
+                                palette_mode=st.palette_mode, color_offset=st.color_offset, color_scale=st.color_scale)
+        whole = (torch.empty((H, W, 4), dtype=torch.float32, device=dev), torch.empty((H, W), dtype=torch.float64, device=dev),
+                 torch.empty((H, W), dtype=torch.int32, device=dev))
+        renderer.render(st, W, H, rgba=whole[0], nu=whole[1], iter=whole[2])
+        assert renderer.last_stages() == 2
+        _band_check(oracle, p, W, H, whole, (0, 3000, 4096, 8188))
+        banded = tuple(torch.full_like(t, -5) for t in whole)
+        R = H // 8
+        for rank in range(8):
+            band = (rank + frame) % 8                                   # FrameExchange: rank r renders band (r + j) mod N
+            sh = fr.Shard(band, 8, R)
+            assert sh.rows(H) == R and int(sh.global_rows(H)[0]) == band * R
+            renderer.render(st, W, H, rgba=banded[0][band * R:(band + 1) * R], nu=banded[1][band * R:(band + 1) * R],
+                            iter=banded[2][band * R:(band + 1) * R], shard=sh)
+        for x, y in zip(whole, banded):
+            assert torch.equal(x, y), frame
+        # the nu payload the ranks ship, recoloured at the destination, is the rendered colour plane bit for bit
+        again = torch.empty_like(whole[0])
+        renderer.colorize(st, banded[1], again)
+        torch.cuda.synchronize()
+        assert torch.equal(again, whole[0])
+        del whole, banded, again
+
+
 def test_strip_gather_pipeline_on_gpu(fr, renderer, oracle):
     """The N > 1 bench path's stream/event pipeline (compute stream -> comm stream, double buffering) on one
     GPU: world size 1 (no process group), strips of 8 rows, three frames submitted back to back."""
@@ -982,3 +1132,14 @@ def test_distinct_contexts_render_concurrently_from_host_threads(fr):
         t.join(120)
     assert not errors, errors
     assert all(len(r) == 12 and all(r) for r in results), results
+
+
+def test_tolerance_exceptions_stay_rare():
+    """Last test of the file: over everything check_against looked at in this session, the pixels accepted through a
+    tolerance exception (fp32 palette wrap, pre-gamma comparison next to black) stay below 0.1 %."""
+    if EXCEPTIONS["pixels"] == 0:
+        pytest.skip("no parity check ran in this session")
+    frac = (EXCEPTIONS["wrap"] + EXCEPTIONS["pre_gamma"]) / EXCEPTIONS["pixels"]
+    print("tolerance exceptions: %d palette-wrap + %d pre-gamma of %d pixels (%.2e); worst single frame %.2e"
+          % (EXCEPTIONS["wrap"], EXCEPTIONS["pre_gamma"], EXCEPTIONS["pixels"], frac, EXCEPTIONS["worst_call"]))
+    assert frac < EXCEPTION_CAP
