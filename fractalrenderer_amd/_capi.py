@@ -20,6 +20,7 @@ FR_ERR_UNSUPPORTED = -4
 FR_ERR_IO = -5
 FR_ERR_PARSE = -6
 FR_ERR_NOMEM = -7
+FR_ERR_INTERNAL = -8
 
 FR_MEM_DEVICE = 0
 FR_MEM_HOST = 1
@@ -82,6 +83,8 @@ SIGNATURES = {
     "fr_render_shard": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, _P(fr_shard), _P(fr_output)]),
     "fr_render_shard_async": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, _P(fr_shard),
                                         _P(fr_output), C.c_void_p]),
+    "fr_ctx_reserve": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, _P(fr_shard)]),
+    "fr_ctx_check": (C.c_int, [C.c_void_p]),
     "fr_ctx_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "fr_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "fr_ctx_last_grid": (C.c_int, [C.c_void_p]),
@@ -90,6 +93,8 @@ SIGNATURES = {
     "fr_colorize_async": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fr_export_rgb8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32]),
     "fr_export_rgb16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32]),
+    "fr_export_rgb8_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "fr_export_rgb16_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32, C.c_void_p]),
     "fr_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, _P(fr_png_text), C.c_int32, C.c_int32]),
     "fr_write_raw_rgb24": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]),
     "fr_frame_path": (C.c_int, [C.c_char_p, C.c_int32, C.c_char_p, C.c_size_t]),

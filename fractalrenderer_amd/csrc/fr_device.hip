@@ -38,9 +38,7 @@ struct fr_ctx {
     size_t stream_bytes[2];
     uint32_t tune_pool;         /* 0 = automatic (currently off), 1 = off, 2 = on: lane-pool kernel */
     uint32_t tune_pool_refill;  /* idle lanes that trigger a refill (0 = 32) */
-    uint32_t tune_pool_evict;   /* retired option, ignored */
     uint32_t tune_periodicity;  /* 0 off; else the lane pool closes orbits that return to their own snapshot (window in iterations) */
-    uint32_t tune_pool_passes;  /* stream pool passes (0 = 1) */
     uint32_t tune_staging;      /* 0 = automatic (currently off), 1 = off (single pass), 2 = on */
     uint32_t tune_stage_first;  /* first budget b0 (0 = 32) */
     uint32_t tune_stage_ratio;  /* budget growth per stage (0 = 4) */
@@ -51,7 +49,6 @@ struct fr_ctx {
     uint32_t tune_run_max;      /* 0 = automatic */
     uint32_t tune_run_min;      /* 0 = automatic */
     int tune_shift_bias;        /* added to the guided-run shift */
-    uint32_t tune_queue_flags;  /* 0 = automatic, else 0x100 | flags */
     uint32_t tune_probes;       /* tile pass: shards a wave probes before exiting (0 = automatic) */
     uint32_t tune_stream_probes;/* same for the stream / lane-pool passes */
     uint32_t tune_stream_rotate;/* 0 automatic, 1 regions by XCD, 2 writers rotate over the regions */
@@ -60,6 +57,11 @@ struct fr_ctx {
     uint32_t tune_shape;        /* 0 = automatic, else FPW_LOG2 (3, 4, 6) */
     void* scratch;              /* device staging for FR_MEM_HOST outputs */
     size_t scratch_bytes;
+    uint32_t debug_region_blocks; /* tests only: cap the capacity of a survivor-stream region, to provoke an overflow */
+    uint32_t* overflow_host;    /* pinned, device-mapped word: a survivor stream ran out of blocks (see StreamRef::overflow) */
+    uint32_t* overflow_dev;     /* the same word as the kernels address it */
+    bool render_on_user_stream; /* the most recent render was enqueued on a caller's stream: ev_end orders the context's
+                                 * own stream (exports, colorize) behind it */
     struct DivCheck { bool valid, julia, f64, ok; uint32_t W, H; };
     DivCheck div_cache[8];      /* exact_division_ok() results */
     uint32_t div_next;
@@ -95,10 +97,13 @@ extern "C" int fr_ctx_create(int device_ordinal, fr_ctx** out)
     if ((e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_begin)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_end)) != hipSuccess ||
-        (e2 = hipMalloc((void**)&c->d_ctrl, kCtrlWords * sizeof(uint32_t))) != hipSuccess) {
+        (e2 = hipMalloc((void**)&c->d_ctrl, kCtrlWords * sizeof(uint32_t))) != hipSuccess ||
+        (e2 = hipHostMalloc((void**)&c->overflow_host, 64, hipHostMallocMapped)) != hipSuccess ||
+        (e2 = hipHostGetDevicePointer((void**)&c->overflow_dev, c->overflow_host, 0)) != hipSuccess) {
         free(c);
         return fr_set_error(FR_ERR_HIP, "context setup failed: %s", hipGetErrorString(e2));
     }
+    *c->overflow_host = 0u;
     *out = c;
     return FR_OK;
 }
@@ -110,6 +115,7 @@ extern "C" void fr_ctx_destroy(fr_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
     (void)hipFree(c->d_ctrl);
+    if (c->overflow_host) (void)hipHostFree(c->overflow_host);
     for (int k = 0; k < 2; ++k) if (c->stream_buf[k]) (void)hipFree(c->stream_buf[k]);
     if (c->frame_buf) (void)hipFree(c->frame_buf);
     if (c->orbit_host) (void)hipHostFree(c->orbit_host);
@@ -152,15 +158,9 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "pool_refill_at")) {
         if (value < 0 || value > 64) return fr_set_error(FR_ERR_INVALID_ARG, "pool_refill_at must be in [0,64]");
         c->tune_pool_refill = (uint32_t)value;
-    } else if (!strcmp(name, "pool_evict_at")) {
-        if (value < 0 || value > 64) return fr_set_error(FR_ERR_INVALID_ARG, "pool_evict_at must be in [0,64]");
-        c->tune_pool_evict = (uint32_t)value;
     } else if (!strcmp(name, "periodicity")) {
         if (value < 0 || value > (1 << 20)) return fr_set_error(FR_ERR_INVALID_ARG, "periodicity must be 0 (off), 1 (on) or a snapshot window in iterations");
         c->tune_periodicity = value == 1 ? 128u : (uint32_t)((value + 15) / 16 * 16);
-    } else if (!strcmp(name, "pool_passes")) {
-        if (value < 0 || value > 8) return fr_set_error(FR_ERR_INVALID_ARG, "pool_passes must be in [0,8]");
-        c->tune_pool_passes = (uint32_t)value;
     } else if (!strcmp(name, "staging")) {
         if (value < 0 || value > 3) return fr_set_error(FR_ERR_INVALID_ARG, "staging must be 0 (automatic), 1 (off), 2 (block stages) or 3 (tile pass + lane-pool pass)");
         c->tune_staging = (uint32_t)value;
@@ -181,14 +181,14 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         c->tune_stream_wg_per_cu = (uint32_t)value;
     } else if (!strcmp(name, "diag_stride")) {
         c->diag_stride = (size_t)value;               /* u64 words between the diag regions of consecutive stages */
-    } else if (!strcmp(name, "queue_flags")) {
-        c->tune_queue_flags = (uint32_t)value;         /* retired (bit-reversed order / claim-ahead): accepted, ignored */
     } else if (!strcmp(name, "probes")) {
         c->tune_probes = (uint32_t)value & 0xFu;
     } else if (!strcmp(name, "stream_probes")) {
         c->tune_stream_probes = (uint32_t)value & 0xFu;
     } else if (!strcmp(name, "stream_rotate")) {
         c->tune_stream_rotate = (uint32_t)value;
+    } else if (!strcmp(name, "debug_region_blocks")) {
+        c->debug_region_blocks = (uint32_t)value;     /* tests only (overflow reporting); 0 = the real capacity */
     } else if (!strcmp(name, "diag_buffer")) {
         c->diag = (uint64_t*)(uintptr_t)value;        /* device pointer, 4 x u64 per wave of the grid; 0 = off */
     } else {
@@ -333,31 +333,55 @@ static uint32_t ceil_log2(uint32_t v)
 static uint32_t* stage_heads(fr_ctx* c, int s) { return c->d_ctrl + (size_t)s * kShards * kShardStrideWords; }
 static uint32_t* stage_counter(fr_ctx* c, int s) { return c->d_ctrl + (size_t)(kMaxStages + s) * kShards * kShardStrideWords; }
 
+/* A survivor stream that ran out of blocks (StreamRef::overflow) loses pixels: report it as a failed render at the
+ * next point where the host knows the kernels are done.  Sticky until reported. */
+static int check_overflow(fr_ctx* c)
+{
+    if (__atomic_load_n(c->overflow_host, __ATOMIC_RELAXED) == 0u) return FR_OK;
+    __atomic_store_n(c->overflow_host, 0u, __ATOMIC_RELAXED);
+    return fr_set_error(FR_ERR_INTERNAL, "a survivor stream overflowed: the frame of the last render on this context is "
+                                         "incomplete (internal sizing error, please report the frame geometry)");
+}
+
+/* Work on the context's own stream (exports, colorize without a stream argument) must see the planes of a render that
+ * was enqueued on a CALLER's stream: ev_end was recorded there behind the last launch. */
+static hipError_t order_after_last_render(fr_ctx* c, hipStream_t s)
+{
+    if (!c->render_on_user_stream || !c->have_timing) return hipSuccess;
+    return hipStreamWaitEvent(s, c->ev_end, 0);
+}
+
 /* Deep_Zoom: what VulkanEngine::prepare_deep_zoom_rendering + dispatch do per frame
  * (src/vk_engine.cpp:215-251, src/compute_effect_manager.h:236-324): recompute the fp64 reference orbit
  * at the view centre on the host (single point, sequential), narrow it to float pairs
  * (src/deep_zoom_system.cpp:102-110), upload, launch the perturbation kernel. */
+/* Deep_Zoom orbit buffers: pinned staging (fp64 orbit + its float narrowing, `cap` scalars each) + the device copy */
+static int reserve_orbit(fr_ctx* c, size_t need)
+{
+    if (need <= c->orbit_cap) return FR_OK;
+    if (c->orbit_host) { (void)hipHostFree(c->orbit_host); c->orbit_host = nullptr; }
+    if (c->orbit_dev) { (void)hipFree(c->orbit_dev); c->orbit_dev = nullptr; }
+    c->orbit_cap = 0;
+    FR_HIP_TRY(hipHostMalloc((void**)&c->orbit_host, need * sizeof(double) + need * sizeof(float)));
+    FR_HIP_TRY(hipMalloc((void**)&c->orbit_dev, need * sizeof(float)));
+    c->orbit_cap = need;
+    return FR_OK;
+}
+
 static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* norm,
-                             uint32_t rows_local, float* rgba, void* nu, int32_t* iter, hipStream_t stream)
+                             uint32_t rows_local, float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only)
 {
     const int32_t max_iter = p->max_iterations;
     int32_t ref_iter = 0;
+    if (reserve_only) return p->use_perturbation ? reserve_orbit(c, (size_t)max_iter * 2) : FR_OK;
     if (p->use_perturbation) {
         const size_t need = (size_t)max_iter * 2;
-        if (need > c->orbit_cap) {
-            /* the pinned staging buffer may still feed an earlier asynchronous upload */
-            FR_HIP_TRY(hipStreamSynchronize(stream));
-            if (c->orbit_host) { (void)hipHostFree(c->orbit_host); c->orbit_host = nullptr; }
-            if (c->orbit_dev) { (void)hipFree(c->orbit_dev); c->orbit_dev = nullptr; }
-            c->orbit_cap = 0;
-            FR_HIP_TRY(hipHostMalloc((void**)&c->orbit_host, need * sizeof(double) + need * sizeof(float)));
-            FR_HIP_TRY(hipMalloc((void**)&c->orbit_dev, need * sizeof(float)));
-            c->orbit_cap = need;
-        } else {
-            FR_HIP_TRY(hipStreamSynchronize(stream));       /* previous upload out of the staging buffer */
-        }
+        /* the pinned staging buffer may still feed an earlier asynchronous upload */
+        FR_HIP_TRY(hipStreamSynchronize(stream));
+        int rs = reserve_orbit(c, need);
+        if (rs != FR_OK) return rs;
         double* xy = (double*)c->orbit_host;
-        float* xyf = (float*)(xy + need);
+        float* xyf = (float*)(xy + c->orbit_cap);
         int st = fr_reference_orbit(p->center_x, p->center_y, max_iter, xy, &ref_iter);
         if (st != FR_OK) return st;
         for (int32_t i = 0; i < 2 * ref_iter; ++i) xyf[i] = (float)xy[i];
@@ -382,8 +406,6 @@ static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t
     q.nsx_shift = -1;
     q.n_items = q.nsx * ((rows_local + 7) / 8);
     q.n_blk = (q.n_items + kShardBlock - 1) / kShardBlock;
-    q.n_blk_padded = q.n_blk;
-    q.blk_rev_shift = 0;
     uint32_t grid = (uint32_t)c->compute_units * 8u;
     const uint32_t max_grid = (q.n_items + 7) / 8;           /* a wave takes at least 2 sub-tiles per dequeue */
     if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
@@ -455,8 +477,6 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
     const uint32_t nsy = (rows_local + fph - 1) / fph;
     tq.n_items = tq.nsx * nsy;
     tq.n_blk = (tq.n_items + kShardBlock - 1) / kShardBlock;
-    tq.n_blk_padded = tq.n_blk;
-    tq.blk_rev_shift = 0;
 
     /* The fp64 tile kernel holds 5 workgroups of 256 threads per CU (the per-wave timeline of the diag buffer
      * shows workgroups beyond the resident set only start when resident ones exit, and find the queue dry):
@@ -541,9 +561,6 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t
         if (nstage >= 2 && max_iter - bounds[nstage - 1] < bounds[nstage - 1] / 4) --nstage;
     }
     bounds[nstage++] = max_iter;
-    /* (follow-up lane-pool passes fed by lanes evicted from the first one -- "pool_passes" -- measured slower
-     * than letting every wave run its lanes out, and carrying the eviction path cost the pool kernel
-     * registers: removed; the option is accepted and ignored) */
     return nstage;
 }
 
@@ -570,9 +587,15 @@ static int reserve_streams(fr_ctx* c, size_t npx, size_t nfields, bool f64, uint
     return FR_OK;
 }
 
+/* reserve_only: do everything a render of this geometry would do BEFORE its first launch -- grow the survivor streams,
+ * the Deep_Zoom orbit buffers, fill the exact-division cache -- and stop (fr_ctx_reserve). */
 static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* shard,
-                          float* rgba, void* nu, int32_t* iter, hipStream_t stream)
+                          float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only = false)
 {
+    if (!reserve_only) {
+        const int ov = check_overflow(c);          /* of an earlier asynchronous render nobody has asked about */
+        if (ov != FR_OK) return ov;
+    }
     fr_shard whole = {0u, 1u, H};
     const fr_shard* sh = shard ? shard : &whole;
     fr_shard norm = *sh;
@@ -583,7 +606,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const uint32_t rows_local = fr_shard_rows(&norm, H);
     if (rows_local == 0) return FR_OK;           /* this part owns no rows */
     if (p->fractal_type == FR_FRACTAL_DEEP_ZOOM)
-        return enqueue_deep_zoom(c, p, W, H, &norm, rows_local, rgba, nu, iter, stream);
+        return enqueue_deep_zoom(c, p, W, H, &norm, rows_local, rgba, nu, iter, stream, reserve_only);
 
     const int fractal = p->fractal_type;                      /* 0 Mandelbrot, 1 Julia, 2 Burning Ship */
     const bool julia = fractal == FR_FRACTAL_JULIA;
@@ -653,7 +676,9 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         const int st = reserve_streams(c, (size_t)rows_local * W, julia ? 2 : 4, f64, grid > sgrid ? grid : sgrid,
                                        nstage > 2 ? 2 : 1, &region_blocks);
         if (st != FR_OK) return st;
+        if (c->debug_region_blocks && c->debug_region_blocks < region_blocks) region_blocks = c->debug_region_blocks;
     }
+    if (reserve_only) return FR_OK;
 
     FR_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, kCtrlWords * sizeof(uint32_t), stream));
     FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
@@ -668,6 +693,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.out.n_blocks = stage_counter(c, 0);
         a.out.region_blocks = region_blocks;
         a.out.rotate = rotate_regions;
+        a.out.overflow = c->overflow_dev;
     }
     a.diag = c->diag;
     hipError_t e;
@@ -705,6 +731,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.out.n_blocks = stage_counter(c, k);
         a.out.region_blocks = region_blocks;
         a.out.rotate = rotate_regions;
+        a.out.overflow = c->overflow_dev;
         memset(&a.q, 0, sizeof(a.q));
         a.q.heads = stage_heads(c, k);
         /* a block of 64 records costs at most (i1 - i0) iterations: uniform, claim a few at a time */
@@ -777,7 +804,27 @@ extern "C" int fr_render_shard_async(fr_ctx* c, const fr_params* p, uint32_t W, 
     if (st <= 0) return st;
     FR_HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    return enqueue_render(c, p, W, H, shard, out->rgba, out->nu, out->iter, s);
+    st = enqueue_render(c, p, W, H, shard, out->rgba, out->nu, out->iter, s);
+    if (st == FR_OK) c->render_on_user_stream = s != c->stream;
+    return st;
+}
+
+extern "C" int fr_ctx_reserve(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* shard)
+{
+    if (!c || !p) return fr_set_error(FR_ERR_INVALID_ARG, "fr_ctx_reserve: ctx/params is NULL");
+    int st = fr_params_validate(p, W, H);
+    if (st != FR_OK) return st;
+    if (shard && shard->nparts && shard->part >= shard->nparts)
+        return fr_set_error(FR_ERR_INVALID_ARG, "shard part %u >= nparts %u", shard->part, shard->nparts);
+    FR_HIP_TRY(hipSetDevice(c->device));
+    FR_HIP_TRY(hipStreamSynchronize(c->stream));           /* growing a buffer frees the old one */
+    return enqueue_render(c, p, W, H, shard, nullptr, nullptr, nullptr, c->stream, true);
+}
+
+extern "C" int fr_ctx_check(fr_ctx* c)
+{
+    if (!c) return fr_set_error(FR_ERR_INVALID_ARG, "ctx is NULL");
+    return check_overflow(c);
 }
 
 extern "C" int fr_render_shard(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
@@ -792,8 +839,9 @@ extern "C" int fr_render_shard(fr_ctx* c, const fr_params* p, uint32_t W, uint32
     if (out->memory == FR_MEM_DEVICE) {
         st = enqueue_render(c, p, W, H, shard, out->rgba, out->nu, out->iter, c->stream);
         if (st != FR_OK) return st;
+        c->render_on_user_stream = false;
         FR_HIP_TRY(hipStreamSynchronize(c->stream));
-        return FR_OK;
+        return check_overflow(c);
     }
     if (out->memory != FR_MEM_HOST)
         return fr_set_error(FR_ERR_INVALID_ARG, "unknown fr_output.memory %d", out->memory);
@@ -819,11 +867,12 @@ extern "C" int fr_render_shard(fr_ctx* c, const fr_params* p, uint32_t W, uint32
     int32_t* d_iter = out->iter ? (int32_t*)(base + off_iter) : nullptr;
     st = enqueue_render(c, p, W, H, &norm, d_rgba, d_nu, d_iter, c->stream);
     if (st != FR_OK) return st;
+    c->render_on_user_stream = false;
     if (out->rgba) FR_HIP_TRY(hipMemcpyAsync(out->rgba, d_rgba, npx * 16, hipMemcpyDeviceToHost, c->stream));
     if (out->nu) FR_HIP_TRY(hipMemcpyAsync(out->nu, d_nu, npx * nu_bytes, hipMemcpyDeviceToHost, c->stream));
     if (out->iter) FR_HIP_TRY(hipMemcpyAsync(out->iter, d_iter, npx * 4, hipMemcpyDeviceToHost, c->stream));
     FR_HIP_TRY(hipStreamSynchronize(c->stream));
-    return FR_OK;
+    return check_overflow(c);
 }
 
 extern "C" int fr_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_output* out)
@@ -843,6 +892,11 @@ extern "C" int fr_colorize_supported(const fr_params* p)
      * Mandelbrot nu = i + 1 - log2(log2|z|) needs |z| > 2 with margin; the Julia form subtracts
      * log2(log|z|^2 / log B) > 1 for any B > 1 */
     if (p->fractal_type == FR_FRACTAL_MANDELBROT ? !(p->bailout >= 2.5f) : !(p->bailout >= 1.25f)) return 0;
+    /* ... and must REPRESENT it: in fp32 a sample escaping at i = max_iter - 1 has nu = RN(max_iter - mu), mu > 0.3,
+     * which rounds up to max_iter itself once the float spacing at max_iter reaches 0.5 (max_iter >= 2^23; mu can be
+     * as small as ~0.3 at the smallest bailouts allowed above, so stop a binade earlier): it would be recoloured as
+     * interior.  fp64 has no such limit at any max_iter the library accepts (<= 2^24). */
+    if (p->precision == FR_PRECISION_F32 && p->max_iterations > (1 << 22)) return 0;
     return 1;
 }
 
@@ -858,6 +912,7 @@ extern "C" int fr_colorize_async(fr_ctx* c, const fr_params* p, uint64_t n_pixel
     if (n_pixels == 0) return FR_OK;
     FR_HIP_TRY(hipSetDevice(c->device));
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (!hip_stream) FR_HIP_TRY(order_after_last_render(c, stream));
     LaunchArgs a;
     fill_params(a, p);
     size_t blocks = ((size_t)n_pixels + kBlockThreads - 1) / kBlockThreads;
@@ -874,17 +929,40 @@ extern "C" int fr_colorize_async(fr_ctx* c, const fr_params* p, uint64_t n_pixel
     return FR_OK;
 }
 
-extern "C" int fr_export_rgb8(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H,
-                              uint8_t* rgb8, int32_t memory, int32_t through_half)
+static size_t export_blocks(const fr_ctx* c, size_t npx)
 {
-    if (!c || !rgba || !rgb8 || W == 0 || H == 0)
-        return fr_set_error(FR_ERR_INVALID_ARG, "fr_export_rgb8: bad argument");
+    size_t blocks = (npx + kBlockThreads - 1) / kBlockThreads;
+    const size_t cap = (size_t)c->compute_units * 8;
+    return blocks > cap ? cap : blocks;
+}
+
+static hipError_t launch_export(const fr_ctx* c, const float4* in, uint8_t* out, uint32_t W, uint32_t H, int through_half,
+                                hipStream_t s)
+{
+    hipLaunchKernelGGL(export_rgb8_kernel, dim3((uint32_t)export_blocks(c, (size_t)W * H)), dim3(kBlockThreads), 0, s,
+                       in, out, (int)W, (int)H, through_half);
+    return hipGetLastError();
+}
+static hipError_t launch_export(const fr_ctx* c, const float4* in, uint16_t* out, uint32_t W, uint32_t H, int through_half,
+                                hipStream_t s)
+{
+    hipLaunchKernelGGL(export_rgb16_kernel, dim3((uint32_t)export_blocks(c, (size_t)W * H)), dim3(kBlockThreads), 0, s,
+                       in, out, (int)W, (int)H, through_half);
+    return hipGetLastError();
+}
+
+/* both export entry points: OUT = uint8_t (8-bit animation frames) or uint16_t (16-bit print export) */
+template <typename OUT>
+static int export_sync(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H, OUT* out, int32_t memory, int32_t through_half,
+                       const char* what)
+{
+    if (!c || !rgba || !out || W == 0 || H == 0) return fr_set_error(FR_ERR_INVALID_ARG, "%s: bad argument", what);
     FR_HIP_TRY(hipSetDevice(c->device));
     const size_t npx = (size_t)W * H;
     const float4* d_in = reinterpret_cast<const float4*>(rgba);
-    uint8_t* d_out = rgb8;
+    OUT* d_out = out;
     if (memory == FR_MEM_HOST) {
-        const size_t need = npx * 16 + npx * 3;
+        const size_t need = npx * 16 + npx * 3 * sizeof(OUT);
         if (need > c->scratch_bytes) {
             if (c->scratch) { (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
             FR_HIP_TRY(hipMalloc(&c->scratch, need));
@@ -892,56 +970,56 @@ extern "C" int fr_export_rgb8(fr_ctx* c, const float* rgba, uint32_t W, uint32_t
         }
         FR_HIP_TRY(hipMemcpyAsync(c->scratch, rgba, npx * 16, hipMemcpyHostToDevice, c->stream));
         d_in = reinterpret_cast<const float4*>(c->scratch);
-        d_out = (uint8_t*)c->scratch + npx * 16;
-    } else if (memory != FR_MEM_DEVICE) {
+        d_out = reinterpret_cast<OUT*>((uint8_t*)c->scratch + npx * 16);
+    } else if (memory == FR_MEM_DEVICE) {
+        /* the plane may come from a render this context enqueued on a caller's stream */
+        FR_HIP_TRY(order_after_last_render(c, c->stream));
+    } else {
         return fr_set_error(FR_ERR_INVALID_ARG, "unknown memory kind %d", memory);
     }
-    size_t blocks = (npx + kBlockThreads - 1) / kBlockThreads;
-    const size_t cap = (size_t)c->compute_units * 8;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(export_rgb8_kernel, dim3((uint32_t)blocks), dim3(kBlockThreads), 0, c->stream,
-                       d_in, d_out, (int)W, (int)H, (int)through_half);
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_export(c, d_in, d_out, W, H, (int)through_half, c->stream);
     if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "export launch failed: %s", hipGetErrorString(e));
     if (memory == FR_MEM_HOST)
-        FR_HIP_TRY(hipMemcpyAsync(rgb8, d_out, npx * 3, hipMemcpyDeviceToHost, c->stream));
+        FR_HIP_TRY(hipMemcpyAsync(out, d_out, npx * 3 * sizeof(OUT), hipMemcpyDeviceToHost, c->stream));
     FR_HIP_TRY(hipStreamSynchronize(c->stream));
+    return check_overflow(c);
+}
+
+template <typename OUT>
+static int export_async(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H, OUT* out, int32_t through_half, void* hip_stream,
+                        const char* what)
+{
+    if (!c || !rgba || !out || W == 0 || H == 0) return fr_set_error(FR_ERR_INVALID_ARG, "%s: bad argument", what);
+    FR_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (!hip_stream) FR_HIP_TRY(order_after_last_render(c, s));
+    hipError_t e = launch_export(c, reinterpret_cast<const float4*>(rgba), out, W, H, (int)through_half, s);
+    if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "export launch failed: %s", hipGetErrorString(e));
     return FR_OK;
+}
+
+extern "C" int fr_export_rgb8(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H,
+                              uint8_t* rgb8, int32_t memory, int32_t through_half)
+{
+    return export_sync<uint8_t>(c, rgba, W, H, rgb8, memory, through_half, "fr_export_rgb8");
 }
 
 extern "C" int fr_export_rgb16(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H,
                                uint16_t* rgb16, int32_t memory, int32_t through_half)
 {
-    if (!c || !rgba || !rgb16 || W == 0 || H == 0)
-        return fr_set_error(FR_ERR_INVALID_ARG, "fr_export_rgb16: bad argument");
-    FR_HIP_TRY(hipSetDevice(c->device));
-    const size_t npx = (size_t)W * H;
-    const float4* d_in = reinterpret_cast<const float4*>(rgba);
-    uint16_t* d_out = rgb16;
-    if (memory == FR_MEM_HOST) {
-        const size_t need = npx * 16 + npx * 6;
-        if (need > c->scratch_bytes) {
-            if (c->scratch) { (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
-            FR_HIP_TRY(hipMalloc(&c->scratch, need));
-            c->scratch_bytes = need;
-        }
-        FR_HIP_TRY(hipMemcpyAsync(c->scratch, rgba, npx * 16, hipMemcpyHostToDevice, c->stream));
-        d_in = reinterpret_cast<const float4*>(c->scratch);
-        d_out = (uint16_t*)((uint8_t*)c->scratch + npx * 16);
-    } else if (memory != FR_MEM_DEVICE) {
-        return fr_set_error(FR_ERR_INVALID_ARG, "unknown memory kind %d", memory);
-    }
-    size_t blocks = (npx + kBlockThreads - 1) / kBlockThreads;
-    const size_t cap = (size_t)c->compute_units * 8;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(export_rgb16_kernel, dim3((uint32_t)blocks), dim3(kBlockThreads), 0, c->stream,
-                       d_in, d_out, (int)W, (int)H, (int)through_half);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "export launch failed: %s", hipGetErrorString(e));
-    if (memory == FR_MEM_HOST)
-        FR_HIP_TRY(hipMemcpyAsync(rgb16, d_out, npx * 6, hipMemcpyDeviceToHost, c->stream));
-    FR_HIP_TRY(hipStreamSynchronize(c->stream));
-    return FR_OK;
+    return export_sync<uint16_t>(c, rgba, W, H, rgb16, memory, through_half, "fr_export_rgb16");
+}
+
+extern "C" int fr_export_rgb8_async(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H, uint8_t* rgb8,
+                                    int32_t through_half, void* hip_stream)
+{
+    return export_async<uint8_t>(c, rgba, W, H, rgb8, through_half, hip_stream, "fr_export_rgb8_async");
+}
+
+extern "C" int fr_export_rgb16_async(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H, uint16_t* rgb16,
+                                     int32_t through_half, void* hip_stream)
+{
+    return export_async<uint16_t>(c, rgba, W, H, rgb16, through_half, hip_stream, "fr_export_rgb16_async");
 }
 
 /* RenderFrameCallback body: src/vk_engine.cpp:1181-1418 (render -> readback -> CPU tonemap/flip -> PNG),
@@ -966,19 +1044,16 @@ extern "C" int fr_render_frame_png(fr_ctx* c, const fr_params* p, uint32_t W, ui
     uint8_t* d_rgb8 = (uint8_t*)c->frame_buf + npx * 16;
     st = enqueue_render(c, &q, W, H, nullptr, d_rgba, nullptr, nullptr, c->stream);
     if (st != FR_OK) return st;
-    size_t blocks = (npx + kBlockThreads - 1) / kBlockThreads;
-    const size_t cap = (size_t)c->compute_units * 8;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(export_rgb8_kernel, dim3((uint32_t)blocks), dim3(kBlockThreads), 0, c->stream,
-                       reinterpret_cast<const float4*>(d_rgba), d_rgb8, (int)W, (int)H, 1);
-    hipError_t e = hipGetLastError();
+    c->render_on_user_stream = false;
+    hipError_t e = launch_export(c, reinterpret_cast<const float4*>(d_rgba), d_rgb8, W, H, 1, c->stream);
     if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "export launch failed: %s", hipGetErrorString(e));
     uint8_t* host = (uint8_t*)malloc(npx * 3);
     if (!host) return fr_set_error(FR_ERR_NOMEM, "out of host memory");
     hipError_t ce = hipMemcpyAsync(host, d_rgb8, npx * 3, hipMemcpyDeviceToHost, c->stream);
     if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
     if (ce != hipSuccess) { free(host); return fr_set_error(FR_ERR_HIP, "readback failed: %s", hipGetErrorString(ce)); }
-    st = fr_write_png(path, W, H, 8, host, nullptr, 0, 0);
+    st = check_overflow(c);
+    if (st == FR_OK) st = fr_write_png(path, W, H, 8, host, nullptr, 0, 0);
     free(host);
     return st;
 }

@@ -36,6 +36,7 @@ const char* fr_status_string(int status)
     case FR_ERR_IO: return "I/O error";
     case FR_ERR_PARSE: return "parse error";
     case FR_ERR_NOMEM: return "out of memory";
+    case FR_ERR_INTERNAL: return "internal error (frame incomplete)";
     default: return "unknown status";
     }
 }

@@ -69,6 +69,9 @@ struct StreamRef {
     uint32_t region_blocks;      /* capacity of one region; 8 regions hold 1.5x the worst-case total */
     uint32_t rotate;             /* writers move to the next region after every block: equal-length regions
                                   * with the same mix of light and heavy blocks (the reader then needs no stealing) */
+    uint32_t* overflow;          /* host-mapped word of the context: set when all 8 regions were found full (the host
+                                  * sizes them for 1.5x the worst case, so this means a sizing bug) -- the records of that
+                                  * block are lost and the render is reported as failed, never silently incomplete */
 };
 
 /* Queue geometry of one launch. */
@@ -78,9 +81,6 @@ struct QueueArgs {
     uint32_t nsx;                /* sub-tiles per sub-tile row                    */
     int32_t  nsx_shift;          /* log2(nsx) when nsx is a power of two, else -1 */
     uint32_t n_blk;              /* blocks of kShardBlock sub-tiles               */
-    uint32_t n_blk_padded;       /* = n_blk (kept for layout; a bit-reversed block order over a padded index
-                                  * space and claim-ahead were measured slower everywhere and removed) */
-    uint32_t blk_rev_shift;      /* unused */
     uint32_t run_shift;          /* run length = clamp(remaining >> run_shift, run_min, run_max) */
     uint32_t run_max, run_min;
     uint32_t flags;              /* bits 4-7: probe limit (kQueueProbeShift) */
@@ -523,7 +523,9 @@ struct RingWriter {
                 return true;
             }
         }
-        return false;                                      /* cannot happen: capacity is worst-case x 1.5 */
+        /* cannot happen (capacity is worst-case x 1.5); if it does, say so: the host fails the render */
+        if (lane == 0 && out.overflow) __hip_atomic_store(out.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
     }
     __device__ __forceinline__ void write_block(uint32_t nvalid)
     {

@@ -90,6 +90,18 @@ class Renderer:
                      ("subtile_shape", shape), ("run_min", run_min), ("shift_bias", shift_bias)):
             self.set_option(k, v)
 
+    def reserve(self, state: FractalState, width: int, height: int, *, fractal_type: FractalType = FractalType.Mandelbrot,
+                precision: Precision = Precision.F64, shard: Optional[Shard] = None) -> None:
+        """fr_ctx_reserve: size the context's scratch for this geometry now, so that later sync=False renders of it
+        (or of anything smaller) are launch-only."""
+        p = state.to_params(fractal_type, precision)
+        sh = shard.to_c() if shard else None
+        _capi.check(self._lib.fr_ctx_reserve(self._ctx, C.byref(p), width, height, C.byref(sh) if sh is not None else None))
+
+    def check(self) -> None:
+        """fr_ctx_check: raises if a render that completed on this context lost pixels (after the caller's own sync)."""
+        _capi.check(self._lib.fr_ctx_check(self._ctx))
+
     def last_grid(self) -> int:
         return _capi.check(self._lib.fr_ctx_last_grid(self._ctx)) & 0xFFFF
 
@@ -199,8 +211,9 @@ class Renderer:
             raise ValueError("colorize needs device tensors")
         _capi.check(self._lib.fr_colorize_async(self._ctx, C.byref(p), n, p_nu, p_rgba, C.c_void_p(stream or 0)))
 
-    def export_rgb16(self, rgba, width: int, height: int, out=None, through_half: bool = False):
-        """16-bit export of export_print_quality (src/vk_engine.cpp:2054-2073): clamp, *65535, flip."""
+    def export_rgb16(self, rgba, width: int, height: int, out=None, through_half: bool = False, stream: Optional[int] = None):
+        """16-bit export of export_print_quality (src/vk_engine.cpp:2054-2073): clamp, *65535, flip.
+        stream (raw hipStream_t, device tensors only): enqueue there and return without waiting (fr_export_rgb16_async)."""
         p_in, kind_in = self._ptr(rgba, "float32", width * height * 4, "rgba")
         if out is None:
             if kind_in == "device":
@@ -213,12 +226,18 @@ class Renderer:
         if kind_in != kind_out:
             raise ValueError("rgba and rgb16 must live in the same memory kind")
         mem = _capi.FR_MEM_DEVICE if kind_in == "device" else _capi.FR_MEM_HOST
-        _capi.check(self._lib.fr_export_rgb16(self._ctx, p_in, width, height, p_out, mem, int(through_half)))
+        if stream is not None:
+            if kind_in != "device":
+                raise ValueError("stream is only meaningful for device tensors")
+            _capi.check(self._lib.fr_export_rgb16_async(self._ctx, p_in, width, height, p_out, int(through_half), C.c_void_p(stream)))
+        else:
+            _capi.check(self._lib.fr_export_rgb16(self._ctx, p_in, width, height, p_out, mem, int(through_half)))
         return out
 
-    def export_rgb8(self, rgba, width: int, height: int, out=None, through_half: bool = False):
+    def export_rgb8(self, rgba, width: int, height: int, out=None, through_half: bool = False, stream: Optional[int] = None):
         """8-bit export of VulkanEngine::render_animation_frame (src/vk_engine.cpp:1344-1371):
-        second ACES + gamma, u8 truncation, vertical flip."""
+        second ACES + gamma, u8 truncation, vertical flip.
+        stream (raw hipStream_t, device tensors only): enqueue there and return without waiting (fr_export_rgb8_async)."""
         p_in, kind_in = self._ptr(rgba, "float32", width * height * 4, "rgba")
         if out is None:
             if kind_in == "device":
@@ -230,7 +249,12 @@ class Renderer:
         if kind_in != kind_out:
             raise ValueError("rgba and rgb8 must live in the same memory kind")
         mem = _capi.FR_MEM_DEVICE if kind_in == "device" else _capi.FR_MEM_HOST
-        _capi.check(self._lib.fr_export_rgb8(self._ctx, p_in, width, height, p_out, mem, int(through_half)))
+        if stream is not None:
+            if kind_in != "device":
+                raise ValueError("stream is only meaningful for device tensors")
+            _capi.check(self._lib.fr_export_rgb8_async(self._ctx, p_in, width, height, p_out, int(through_half), C.c_void_p(stream)))
+        else:
+            _capi.check(self._lib.fr_export_rgb8(self._ctx, p_in, width, height, p_out, mem, int(through_half)))
         return out
 
 

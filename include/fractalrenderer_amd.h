@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define FR_VERSION_MAJOR 0
-#define FR_VERSION_MINOR 1
+#define FR_VERSION_MINOR 2
 
 typedef enum fr_status {
     FR_OK               =  0,
@@ -37,7 +37,8 @@ typedef enum fr_status {
     FR_ERR_UNSUPPORTED  = -4,   /* fractal type outside the hot path (Mandelbrot, JuliaSet, Deep_Zoom are in) */
     FR_ERR_IO           = -5,   /* .franim file could not be read / written */
     FR_ERR_PARSE        = -6,   /* .franim JSON malformed or a required key is missing */
-    FR_ERR_NOMEM        = -7
+    FR_ERR_NOMEM        = -7,
+    FR_ERR_INTERNAL     = -8    /* the library caught itself out (a survivor stream overflowed): the frame is incomplete */
 } fr_status;
 
 /* FractalType, src/fractal_state.h:6-14 (same numeric values).  Mandelbrot and JuliaSet are the
@@ -187,10 +188,31 @@ int fr_render_shard(fr_ctx* ctx, const fr_params* p, uint32_t width, uint32_t he
                     const fr_shard* shard, const fr_output* out);
 
 /* Asynchronous form for frame pipelining: enqueues on `hip_stream` (a hipStream_t passed
- * as void*; NULL = the context's own stream) and returns without waiting.  Device memory
- * only.  Launch-only: no allocation, no synchronisation (graph-capture safe). */
+ * as void*; NULL = the context's own stream) and returns without waiting.  Device memory only.
+ * STEADY STATE it is launch-only (one memset node + the kernel launches + two event records: no
+ * allocation, no host synchronisation, capturable into a hipGraph).  What is not steady state:
+ *   - the first render of a geometry LARGER than any before it on this context grows the context's
+ *     survivor-stream scratch (hipFree + hipMalloc), and the first render of a new (W, H, fractal,
+ *     precision) checks on the host that the divide-free viewport map is exact for every column and row
+ *     (a loop over W + H numerators, cached for 8 geometries).  fr_ctx_reserve() does both ahead of time;
+ *   - Deep_Zoom with use_perturbation recomputes the fp64 reference orbit on the host for every frame, as
+ *     the reference does (src/vk_engine.cpp:215-251), and waits for `hip_stream` before reusing its pinned
+ *     upload buffer: never launch-only.
+ * A failure the device reports later (FR_ERR_INTERNAL) surfaces at the next call on the context or
+ * through fr_ctx_check(). */
 int fr_render_shard_async(fr_ctx* ctx, const fr_params* p, uint32_t width, uint32_t height,
                           const fr_shard* shard, const fr_output* out, void* hip_stream);
+
+/* Pre-sizes everything a render of (params, width, height, shard) allocates or caches on first use, so
+ * that later fr_render_shard_async calls of this or any smaller geometry are launch-only (see there).
+ * Synchronises the context's own stream.  New design: the reference allocates its image and staging
+ * buffer per call (src/vk_engine.cpp:1197-1221,1268-1272). */
+int fr_ctx_reserve(fr_ctx* ctx, const fr_params* p, uint32_t width, uint32_t height, const fr_shard* shard);
+
+/* FR_OK, or FR_ERR_INTERNAL if a render that has completed on this context since the last call lost
+ * pixels (cleared by the call).  The synchronous entry points check by themselves; a caller of the
+ * _async forms calls this after it has synchronised its stream. */
+int fr_ctx_check(fr_ctx* ctx);
 
 /* Device time of the most recent render's kernel on this context, from a HIP event pair
  * recorded around the launch on the launch stream (blocks until that kernel is done).
@@ -203,9 +225,7 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "run_max", "run_min" longest / shortest run of sub-tiles one dequeue may claim
  *   "shift_bias"         signed change of log2 of the guided-run divisor
  *   "pool"               2 = lane-pool kernel (lanes are refilled with the next pixel as they finish),
- *                        1 = off, 0 = automatic;  "pool_refill_at" = idle lanes that trigger a refill;
- *                        "pool_passes", "pool_evict_at": retired (follow-up passes fed by evicted lanes measured
- *                        slower and were removed); accepted and ignored
+ *                        1 = off, 0 = automatic;  "pool_refill_at" = idle lanes that trigger a refill
  *   "staging"            3 = tile pass for the first "stage_first" iterations + ONE lane-pool pass over the
  *                        compacted survivors to max_iter, 2 = tile pass + block stream passes, 1 = single pass,
  *                        0 = automatic: 3 where it applies (no SSAA, no trap/stripe effects) and pays off --
@@ -215,8 +235,6 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "stage_ratio"        budget growth per stream pass (default 4)
  *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue may claim in a stream pass
  *   "stream_workgroups_per_cu"          workgroups per compute unit of the stream pass
- *   "queue_flags"        retired: bit-reversed tile order and claim-ahead measured slower everywhere and were
- *                        removed from the kernels; the option is accepted and ignored
  *   "probes", "stream_probes"  queue shards a wave tries before it exits, tile pass / stream passes
  *                        (1..8; 0 = automatic: 1 for a staged or short-orbit tile pass, 4 for stream passes,
  *                        all 8 otherwise and on grids of fewer than 64 workgroups)
@@ -232,6 +250,8 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                        counterpart: the shaders iterate every interior sample to max_iter.  Off by default so
  *                        that the default path executes exactly the reference's iteration count.
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1
+ *   "debug_region_blocks" tests only: caps the capacity of a survivor-stream region so that the overflow report
+ *                        (FR_ERR_INTERNAL) can be exercised; 0 = the real capacity (1.5x the worst case)
  *   "diag_buffer"        device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks,
  *                        items processed, dequeues); 0 disables.  "diag_stride" = uint64 words
  *                        between the regions of consecutive stages
@@ -254,7 +274,8 @@ int fr_ctx_compute_units(fr_ctx* ctx);
  *
  * fr_colorize_supported: 1 when that holds for `params` (Mandelbrot / JuliaSet / BurningShip, no
  * trap / stripe / interior-style variant, antialiasing_samples <= 1, bailout large enough that
- * nu == max_iterations identifies exactly the interior samples), else 0.
+ * nu == max_iterations identifies exactly the interior samples, and for FR_PRECISION_F32 max_iterations
+ * <= 2^22 so that a float nu just below max_iterations does not round up to it), else 0.
  * fr_colorize_async: nu (n_pixels doubles for FR_PRECISION_F64, floats for F32) -> rgba (n_pixels x
  * RGBA f32), both device pointers, enqueued on hip_stream (NULL: the context's stream), no host sync;
  * FR_FLAG_POST_CHAIN applies the post chain as fr_render does.  FR_ERR_UNSUPPORTED when not supported. */
@@ -276,6 +297,16 @@ int fr_export_rgb8(fr_ctx* ctx, const float* rgba, uint32_t width, uint32_t heig
  * RGBA f32 in -> packed RGB16 (host-endian uint16, rows*W*3) out. */
 int fr_export_rgb16(fr_ctx* ctx, const float* rgba, uint32_t width, uint32_t height,
                     uint16_t* rgb16, int32_t memory, int32_t through_half);
+
+/* Stream ordering of the two exports above (and of fr_colorize_async with a NULL stream): they run on the
+ * context's own stream, ordered behind the most recent render of THIS context whatever stream that was
+ * enqueued on; a plane produced by anything else (another context, torch) must be complete, or the caller
+ * uses the _async forms below on the producing stream.  The _async forms: device memory only, enqueued on
+ * `hip_stream` (NULL = the context's stream), no host synchronisation. */
+int fr_export_rgb8_async(fr_ctx* ctx, const float* rgba, uint32_t width, uint32_t height, uint8_t* rgb8,
+                         int32_t through_half, void* hip_stream);
+int fr_export_rgb16_async(fr_ctx* ctx, const float* rgba, uint32_t width, uint32_t height, uint16_t* rgb16,
+                          int32_t through_half, void* hip_stream);
 
 /* ---- frame output (reference f3) ---------------------------------------------------------- */
 

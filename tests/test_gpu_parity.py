@@ -323,7 +323,7 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
     p, W, H = CASES["seahorse_0008_f64"]
     base = gpu_render(fr, renderer, p, 200, 120)
     assert renderer.last_stages() == 2                     # default: tile pass + lane-pool pass
-    opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "queue_flags", "stream_workgroups_per_cu", "pool_refill_at", "pool_passes", "pool_evict_at",
+    opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "stream_workgroups_per_cu", "pool_refill_at",
             "probes", "stream_probes", "stream_rotate")
     try:
         for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
@@ -334,15 +334,13 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
         renderer.set_tuning()
         for kw in (dict(staging=1), dict(staging=2), dict(staging=2, stage_first=16), dict(staging=2, stage_first=64, stage_ratio=2),
                    dict(staging=2, stage_ratio=16), dict(staging=2, stage_first=512), dict(staging=2, stream_run_max=1),
-                   dict(queue_flags=0x100), dict(queue_flags=0x103), dict(staging=2, queue_flags=0x103),
                    dict(probes=8), dict(probes=2), dict(probes=1, stream_probes=1), dict(staging=1, probes=1),
                    dict(staging=2, probes=3, stream_probes=2), dict(stream_rotate=1), dict(stream_rotate=1, stream_probes=1),
                    dict(stream_rotate=2, stream_probes=8), dict(staging=2, stream_rotate=1),
 
-                   dict(staging=2, stage_first=16, stage_ratio=2, queue_flags=0x101, stream_workgroups_per_cu=2),
+                   dict(staging=2, stage_first=16, stage_ratio=2, stream_workgroups_per_cu=2),
                    dict(staging=3), dict(staging=3, stage_first=64, pool_refill_at=8), dict(staging=3, stage_first=16, pool_refill_at=64),
-                   dict(staging=3, stream_run_max=1, stream_workgroups_per_cu=1), dict(staging=3, pool_passes=1),
-                   dict(staging=3, pool_passes=5, pool_evict_at=64), dict(staging=3, pool_passes=2, pool_evict_at=1, pool_refill_at=1)):
+                   dict(staging=3, stream_run_max=1, stream_workgroups_per_cu=1), dict(staging=3, pool_refill_at=1)):
             for k, v in kw.items():
                 renderer.set_option(k, v)
             cur = gpu_render(fr, renderer, p, 200, 120)
@@ -390,20 +388,17 @@ def test_lane_pool_larger_frames_and_shards(fr, renderer, oracle, name):
         tile = gpu_render(fr, renderer, p, W, H)
         tile_sh = gpu_render(fr, renderer, p, W, H, shard=fr.Shard(1, 3, 8))
         renderer.set_option("pool", 2)
-        for shape, flags in ((3, 0), (6, 0x103), (4, 0x100)):
+        for shape in (3, 6, 4):
             renderer.set_tuning(shape=shape)
-            renderer.set_option("queue_flags", flags)
             pool = gpu_render(fr, renderer, p, W, H)
             for a, b in zip(tile, pool):
                 assert np.array_equal(a, b)
         renderer.set_tuning()
-        renderer.set_option("queue_flags", 0)
         pool_sh = gpu_render(fr, renderer, p, W, H, shard=fr.Shard(1, 3, 8))
         for a, b in zip(tile_sh, pool_sh):
             assert np.array_equal(a, b)
     finally:
         renderer.set_option("pool", 0)
-        renderer.set_option("queue_flags", 0)
         renderer.set_option("staging", 0)
         renderer.set_tuning()
 
@@ -1132,6 +1127,111 @@ def test_distinct_contexts_render_concurrently_from_host_threads(fr):
         t.join(120)
     assert not errors, errors
     assert all(len(r) == 12 and all(r) for r in results), results
+
+
+def test_overflow_of_a_survivor_stream_is_reported_not_swallowed(fr, oracle):
+    """A survivor stream that runs out of blocks loses pixels.  The capacity is 1.5x the worst case, so it takes the
+    tests-only option "debug_region_blocks" to get there -- and then the render must FAIL (FR_ERR_INTERNAL), in the
+    synchronous call itself and, for an asynchronous render, at fr_ctx_check() / the next call; and the context must
+    be usable again afterwards."""
+    import torch
+    r = fr.Renderer(0)
+    try:
+        st = fr.FractalState(max_iterations=1024, zoom=1.5)               # 60 % interior: most pixels survive the tile pass
+        W, H = 512, 384
+        nu = torch.empty((H, W), dtype=torch.float64, device="cuda:0")
+        r.render(st, W, H, nu=nu)
+        good = nu.clone()
+        r.set_option("debug_region_blocks", 1)                            # 8 regions x 1 block = 512 records
+        with pytest.raises(fr.FractalRendererError) as e:
+            r.render(st, W, H, nu=nu)
+        assert e.value.status == fr._capi.FR_ERR_INTERNAL and "overflow" in str(e.value)
+        s = torch.cuda.Stream()
+        r.render(st, W, H, nu=nu, sync=False, stream=s.cuda_stream)       # asynchronous: nothing to report yet
+        s.synchronize()
+        with pytest.raises(fr.FractalRendererError) as e:
+            r.check()
+        assert e.value.status == fr._capi.FR_ERR_INTERNAL
+        r.check()                                                          # reported once, then clear
+        r.render(st, W, H, nu=nu, sync=False, stream=s.cuda_stream)
+        s.synchronize()
+        r.set_option("debug_region_blocks", 0)
+        with pytest.raises(fr.FractalRendererError):                       # ... or it surfaces at the next call
+            r.render(st, W, H, nu=nu)
+        r.render(st, W, H, nu=nu)
+        assert torch.equal(nu, good)
+    finally:
+        r.close()
+
+
+def test_reserved_async_render_is_launch_only(fr, oracle):
+    """The header's contract for fr_render_shard_async after fr_ctx_reserve: no allocation, no host synchronisation --
+    shown the hard way, by capturing the call into a HIP graph (a hipMalloc / hipFree / stream synchronise inside a
+    capture is an error) on a context that has never rendered, and replaying the graph."""
+    import torch
+    W, H = 1000, 700
+    for kw, ft, prec, dt in ((dict(max_iterations=1024), fr.FractalType.Mandelbrot, fr.Precision.F64, torch.float64),
+                             (dict(max_iterations=2048, center_x=0.0, julia_c_real=-0.8, julia_c_imag=0.156),
+                              fr.FractalType.JuliaSet, fr.Precision.F32, torch.float32)):
+        st = fr.FractalState(**kw)
+        ref = fr.Renderer(0)
+        want_nu = torch.empty((H, W), dtype=dt, device="cuda:0")
+        want_rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+        ref.render(st, W, H, fractal_type=ft, precision=prec, nu=want_nu, rgba=want_rgba)
+        ref.close()
+        r = fr.Renderer(0)
+        try:
+            r.reserve(st, W, H, fractal_type=ft, precision=prec)
+            free0, _ = torch.cuda.mem_get_info()
+            nu = torch.zeros_like(want_nu)
+            rgba = torch.zeros_like(want_rgba)
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            with torch.cuda.graph(g, stream=side):
+                r.render(st, W, H, fractal_type=ft, precision=prec, nu=nu, rgba=rgba, sync=False,
+                         stream=torch.cuda.current_stream().cuda_stream)
+            for _ in range(3):
+                nu.fill_(-1.0)
+                rgba.fill_(-1.0)
+                g.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(nu, want_nu) and torch.equal(rgba, want_rgba)
+                r.check()
+            free1, _ = torch.cuda.mem_get_info()
+            assert free0 - free1 < (4 << 20)            # the graph's own bookkeeping, no scratch growth
+            del g
+        finally:
+            r.close()
+
+
+def test_export_is_ordered_behind_a_render_on_the_callers_stream(fr):
+    """fr_export_rgb8 runs on the context's own (non-blocking) stream; the render that produced its input may have been
+    enqueued on a caller's stream.  The export must wait for it: no host synchronisation in between here."""
+    import torch
+    W = H = 2048
+    st = fr.FractalState(max_iterations=1024, zoom=1.5)                   # ~0.6 ms of rendering
+    r = fr.Renderer(0)
+    try:
+        rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+        r.render(st, W, H, rgba=rgba)
+        want8 = r.export_rgb8(rgba, W, H, through_half=True).clone()
+        want16 = r.export_rgb16(rgba, W, H).clone()
+        user = torch.cuda.Stream()
+        for _ in range(5):
+            with torch.cuda.stream(user):
+                rgba.zero_()
+            r.render(st, W, H, rgba=rgba, sync=False, stream=user.cuda_stream)
+            got8 = r.export_rgb8(rgba, W, H, through_half=True)            # context stream, behind ev_end of the render
+            assert torch.equal(got8, want8)
+            with torch.cuda.stream(user):
+                rgba.zero_()
+            r.render(st, W, H, rgba=rgba, sync=False, stream=user.cuda_stream)
+            got16 = torch.empty_like(want16)
+            r.export_rgb16(rgba, W, H, out=got16, stream=user.cuda_stream)  # the _async form on the producing stream
+            user.synchronize()
+            assert torch.equal(got16, want16)
+    finally:
+        r.close()
 
 
 def test_tolerance_exceptions_stay_rare():

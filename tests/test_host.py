@@ -33,7 +33,7 @@ def test_struct_layout_matches_header(fr):
     assert C.sizeof(fr._capi.fr_output) == 32 and C.sizeof(fr._capi.fr_shard) == 12
     major, minor = C.c_int(), C.c_int()
     fr.lib().fr_version(C.byref(major), C.byref(minor))
-    assert (major.value, minor.value) == (0, 1)
+    assert (major.value, minor.value) == (0, 2)
 
 
 def test_no_device_fails_loudly(fr):
@@ -568,3 +568,23 @@ def test_bench_workloads_and_cpu_baseline_leg(oracle):
     b = bench.cpu_baseline(w)
     assert b["kind"] == "port" and b["unit"] == "Mpixels/s" and b["cores"] >= 1 and b["value"] > 0
     assert "sample" in b and "oracle" in b["sample"]
+
+
+def test_colorize_supported_stops_where_a_float_nu_can_round_up_to_max_iter(fr):
+    """fr_colorize_supported tells the multi-GPU exchange that it may ship the nu plane and recolour it, reading
+    'interior' off nu == max_iter.  In fp32 a sample escaping at i = max_iter - 1 has nu = RN(max_iter - mu): once the
+    float spacing at max_iter reaches 1 (max_iter >= 2^23) that IS max_iter and the pixel would be painted as interior.
+    The library must refuse the shortcut from 2^22 on (one binade of margin) in fp32 and keep it in fp64."""
+    import numpy as np
+    L = fr.lib()
+    for prec, mi, want in ((fr.Precision.F32, 1 << 22, 1), (fr.Precision.F32, (1 << 22) + 1, 0), (fr.Precision.F32, 1 << 24, 0),
+                           (fr.Precision.F64, 1 << 24, 1), (fr.Precision.F32, 2048, 1)):
+        for ft in (fr.FractalType.Mandelbrot, fr.FractalType.JuliaSet, fr.FractalType.BurningShip):
+            p = fr.FractalState(max_iterations=mi).to_params(ft, prec)
+            assert L.fr_colorize_supported(C.byref(p)) == want, (prec, mi, ft)
+    # the arithmetic behind the limit: smallest mu the supported bailouts allow is ~0.32 (Mandelbrot, bailout 2.5:
+    # mu = log2(log2 |z|) with |z| just above 2.5)
+    mu = np.log2(np.log2(2.5))
+    assert 0.3 < mu < 0.5
+    assert np.float32(np.float32(1 << 22) - np.float32(mu)) < np.float32(1 << 22)        # still below: representable
+    assert np.float32(np.float32(1 << 24) - np.float32(mu)) == np.float32(1 << 24)       # rounds up: the hazard
