@@ -183,6 +183,8 @@ def parse_args(argv=None):
                          "default command only contains the one-frame-at-a-time launches the roofline is quoted on)")
     ap.add_argument("--no-periodicity", action="store_true",
                     help="skip the informational leg with the library's exact cycle closing switched on")
+    ap.add_argument("--options", default="", help="fr_ctx_set_option pairs for every render context, 'name=value,name=value' "
+                                                  "(A/B runs and profiles of non-default schedules)")
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--run-max", type=int, default=0)
     ap.add_argument("--shape", type=int, default=0)
@@ -341,8 +343,15 @@ def main() -> None:
     state = fr.FractalState(**w["state"])
     ftype = fr.FractalType[w["fractal"]]
     prec = fr.Precision[w["precision"]]
-    r = fr.Renderer(local_rank)
-    r.set_tuning(args.wg_per_cu, args.run_max, args.shape)
+    def new_renderer():
+        rr = fr.Renderer(local_rank)
+        rr.set_tuning(args.wg_per_cu, args.run_max, args.shape)
+        for kv in filter(None, args.options.split(",")):
+            k, v = kv.split("=")
+            rr.set_option(k.strip(), int(v, 0))
+        return rr
+
+    r = new_renderer()
 
     def barrier():
         torch.cuda.synchronize()
@@ -410,8 +419,7 @@ def main() -> None:
 
         dt_pipe = None
         if args.pipelined:
-            r2 = fr.Renderer(local_rank)
-            r2.set_tuning(args.wg_per_cu, args.run_max, args.shape)
+            r2 = new_renderer()
             rgba2 = torch.empty_like(rgba)
             stream2 = torch.cuda.Stream(device=dev)
             pair = ((r, rgba, h), (r2, rgba2, stream2.cuda_stream))
@@ -490,9 +498,7 @@ def main() -> None:
         fx = FrameExchange(W, H, payload=payload, nu_dtype=nu_dtype, device=dev, rows_per_strip=args.rows_per_strip,
                            render_lanes=lanes, layout=args.layout)
         # one render context per lane: a context is not re-entrant, distinct contexts run concurrently
-        ctxs = [r] + [fr.Renderer(local_rank) for _ in range(lanes - 1)]
-        for c in ctxs[1:]:
-            c.set_tuning(args.wg_per_cu, args.run_max, args.shape)
+        ctxs = [r] + [new_renderer() for _ in range(lanes - 1)]
 
         def render_fn(shard, out, _frame, plane, lane=0):
             kw = {"nu": out} if plane == "nu" else {"rgba": out}

@@ -20,6 +20,7 @@
 using namespace fr;
 
 static constexpr int kMaxStages = 16;
+static constexpr uint32_t kAutoStaging = 3u;   /* "staging" = 0: tile pass + lane-pool pass (4, the fused launch, measured slower on whole frames) */
 static constexpr size_t kCtrlWords = (size_t)2 * kMaxStages * kShards * kShardStrideWords;
 
 struct fr_ctx {
@@ -162,7 +163,7 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         if (value < 0 || value > (1 << 20)) return fr_set_error(FR_ERR_INVALID_ARG, "periodicity must be 0 (off), 1 (on) or a snapshot window in iterations");
         c->tune_periodicity = value == 1 ? 128u : (uint32_t)((value + 15) / 16 * 16);
     } else if (!strcmp(name, "staging")) {
-        if (value < 0 || value > 3) return fr_set_error(FR_ERR_INVALID_ARG, "staging must be 0 (automatic), 1 (off), 2 (block stages) or 3 (tile pass + lane-pool pass)");
+        if (value < 0 || value > 4) return fr_set_error(FR_ERR_INVALID_ARG, "staging must be 0 (automatic), 1 (single pass), 2 (block stages), 3 (tile pass + lane-pool pass) or 4 (fused: one launch)");
         c->tune_staging = (uint32_t)value;
     } else if (!strcmp(name, "stage_first")) {
         if (value < 0 || value > (1 << 24)) return fr_set_error(FR_ERR_INVALID_ARG, "stage_first out of range");
@@ -298,6 +299,16 @@ static hipError_t launch_stream_pool(dim3 grid, hipStream_t s, const LaunchArgs&
         hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, true, true>), grid, dim3(kBlockThreads), 0, s, a);
     else
         hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, true, false>), grid, dim3(kBlockThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+template <typename T, int FRACTAL>
+static hipError_t launch_fused(dim3 grid, hipStream_t s, const LaunchArgs& a)
+{
+    if (a.period_window)
+        hipLaunchKernelGGL((fused_kernel<T, FRACTAL, true>), grid, dim3(kBlockThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL((fused_kernel<T, FRACTAL, false>), grid, dim3(kBlockThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -534,8 +545,8 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t
     int nstage = 0;
     /* automatic = tile pass + one lane-pool pass (staging 3): measured faster than the single pass on
      * C2 (+5 %), C3 (+30 %), C5 (+40 %), 1 % slower on C4 (profiles/r01_staging_sweeps.txt) */
-    const uint32_t mode = c->tune_staging ? c->tune_staging : 3u;
-    const bool allow = !effects && p->antialiasing_samples <= 1 && (mode == 2 || mode == 3);
+    const uint32_t mode = c->tune_staging ? c->tune_staging : kAutoStaging;
+    const bool allow = !effects && p->antialiasing_samples <= 1 && (mode == 2 || mode == 3 || mode == 4);
     /* tile-pass budget: ~max_iter/28 rounded to the unchecked block, within [32, 192] (measured best:
      * 32 at max_iter 1024, 64 at 2048, 128-192 at 4096, flat at 16384) */
     int auto_first = ((max_iter / 28 + kFastBlock / 2) / kFastBlock) * kFastBlock;
@@ -555,7 +566,7 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t
         while (b < max_iter && nstage < kMaxStages - 1) {
             bounds[nstage++] = (int)b;
             b *= ratio;
-            if (mode == 3) break;                                /* tile pass + lane-pool passes to max_iter */
+            if (mode == 3 || mode == 4) break;                   /* tile stage + lane pool to max_iter */
         }
         /* do not leave a last stage much shorter than the one before it */
         if (nstage >= 2 && max_iter - bounds[nstage - 1] < bounds[nstage - 1] / 4) --nstage;
@@ -646,16 +657,19 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      * long with the same mix of blocks, so the reading pass is balanced with little stealing (measured,
      * profiles/r01_region_rotation.txt: C2 0.883 -> 0.831 ms, C3 0.598 -> 0.539 ms; regions by XCD = 1) */
     const uint32_t rotate_regions = c->tune_stream_rotate == 1u ? 0u : 1u;
-    const bool pool_stream = staged && (c->tune_staging ? c->tune_staging : 3u) == 3u;
+    const int shape = c->tune_shape ? (int)c->tune_shape : 3;
+    uint32_t stage_mode = c->tune_staging ? c->tune_staging : kAutoStaging;
+    if (stage_mode == 4u && shape != 3) stage_mode = 3u;     /* the fused kernel exists for 8x8 sub-tiles only */
+    const bool pool_stream = staged && stage_mode == 3u;
+    const bool fused = staged && stage_mode == 4u;           /* both stages in one launch, hand-off inside the wave */
 
     /* bounded, cheap items: the staged tile pass, and an unstaged pass whose samples run at most 128 updates
      * (measured at max_iter <= 32: 0.31 ms with short runs -- the queue words saturate -- 0.17 ms with long) */
     const int aa1 = p->antialiasing_samples > 1 ? p->antialiasing_samples : 1;
-    const bool bounded = staged || (!effects && (long long)max_iter * aa1 * aa1 <= 128);
+    const bool bounded = (staged && !fused) || (!effects && (long long)max_iter * aa1 * aa1 <= 128);
     /* items of moderate cost (an unstaged pass below the staging threshold): short runs as for unbounded items, but
      * the waves stop at their home shard -- the blocks of 16 sub-tiles dealt round-robin keep the shards level */
     const bool moderate = !staged && !effects && (long long)max_iter * aa1 * aa1 < 768;
-    const int shape = c->tune_shape ? (int)c->tune_shape : 3;
     uint32_t grid = 0, waves_per_shard = 0;
     const QueueArgs tq = plan_tile_queue(c, W, rows_local, shape, bounded, moderate, &grid, &waves_per_shard);
     auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
@@ -672,7 +686,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         if (sgrid > cap) sgrid = cap < 1u ? 1u : cap;
     }
     uint32_t region_blocks = 0;
-    if (staged) {
+    if (staged && !fused) {
         const int st = reserve_streams(c, (size_t)rows_local * W, julia ? 2 : 4, f64, grid > sgrid ? grid : sgrid,
                                        nstage > 2 ? 2 : 1, &region_blocks);
         if (st != FR_OK) return st;
@@ -688,6 +702,25 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.q.heads = stage_heads(c, 0);
     a.i0 = 0;
     a.i1 = bounds[0];
+    if (fused) {
+        /* An interior sub-tile is 64 x (max_iter - b0) updates: claim few at a time, one at a time towards the end
+         * of the queue (what a wave holds in reserve when the queue runs dry is the tail of the launch). */
+        a.q.run_min = c->tune_run_min ? c->tune_run_min : 1u;
+        a.q.run_max = c->tune_run_max ? c->tune_run_max : 4u;
+        if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
+        a.q.run_shift = clamp_shift((int)ceil_log2(4u * waves_per_shard));
+        a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
+        if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
+        a.period_window = c->tune_periodicity;
+        a.diag = c->diag;
+        hipError_t ef = by_variant(fractal, f64, [&](auto t, auto f) {
+            return launch_fused<decltype(t), decltype(f)::value>(dim3(grid), stream, a); });
+        if (ef != hipSuccess) return fr_set_error(FR_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString(ef));
+        FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
+        c->have_timing = true;
+        c->last_stages = 2;
+        return FR_OK;
+    }
     if (staged) {
         a.out.base = (uint8_t*)c->stream_buf[0];
         a.out.n_blocks = stage_counter(c, 0);

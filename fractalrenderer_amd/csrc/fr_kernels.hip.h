@@ -1565,6 +1565,338 @@ pool_kernel(const LaunchArgs A)
     }
 }
 
+/* ---- fused pass: tile stage + lane pool in ONE persistent launch, hand-off inside the wave -----------------------
+ *
+ * Every WAVE is both stages of the two-launch schedule (tile_kernel, then pool_kernel over the compacted survivors):
+ *
+ *   - POOL STATE: 64 persistent lanes, as pool_kernel: a lane holds one sample, runs it towards max_iter in the
+ *     wave-uniform loops (unchecked blocks of 16 updates with rollback + tested replay), is retired (shaded, stored)
+ *     when it escapes or reaches its deadline, and is refilled;
+ *   - TILE STAGE: when the wave's survivor ring (LDS, wave-private, 128 records) holds fewer records than the wave
+ *     has free lanes, the wave takes the next 8x8 sub-tile of its reserve (runs of sub-tiles claimed from the
+ *     XCD-sharded queue, one atomicAdd per run), maps its 64 pixels, runs their first b0 updates with the
+ *     wave-uniform early-out, shades and stores (coalesced, whole 128-byte lines) the pixels that escaped and
+ *     appends the survivors to the ring -- while its pool lanes wait in their registers;
+ *   - the free lanes are refilled from the ring (ds_reads; every record has run exactly b0 updates, so a refilled
+ *     lane gets the LATEST deadline of the wave and the earliest one only changes when it is reached).
+ *
+ * The hand-off never leaves the wave: no survivor stream in HBM (C2: 131 MB written + read per frame, 4 GB less
+ * scratch at 8192^2), no counters, no cross-workgroup visibility protocol, one launch.  What it costs: a sub-tile
+ * inside the set is 64 x (max_iter - b0) updates -- one "generation" of a wave, 80 us on C2 -- and it stays with the
+ * wave that claimed it, so waves end the launch with different backlogs (ring + reserve) and the last tenth of the
+ * launch runs on a nearly empty chip.  Measured: its throughput phase is VALU-issue bound like
+ * the two launches' pool pass, its tail is longer; the two-launch schedule stays the default for whole frames.
+ * Per-lane operation sequence = tile_kernel + pool_kernel: every plane is bit-identical to theirs. */
+template <typename T, int FRACTAL, bool PERIOD>
+__global__ void __launch_bounds__(kBlockThreads)
+fused_kernel(const LaunchArgs A)
+{
+    constexpr int FPW_LOG2 = 3, FPW = 8, FPH = 8;
+    constexpr int NF = RecFields<FRACTAL>::n;
+    constexpr bool ABS = Form<FRACTAL>::abs_step;
+
+    __shared__ LdsBlock S;
+    __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
+    stage_constants(S, A);
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const int lx = (int)(lane & (FPW - 1)), ly = (int)(lane >> FPW_LOG2);
+    const int W = A.W, max_iter = A.max_iter, b0 = A.i1;
+    const T center_x = (T)S.center_x, center_y = (T)S.center_y, zoom = (T)S.zoom;
+    const T bailout = (T)S.bailout;
+    const T B2 = bailout * bailout;
+    const T B2x4 = T(4) * B2;
+    const T resx = (T)W, resy = (T)A.H;
+    const T inv_w = sizeof(T) == 8 ? (T)A.inv_w_d : (T)A.inv_w_f;
+    const T inv_h = sizeof(T) == 8 ? (T)A.inv_h_d : (T)A.inv_h_f;
+    const T aspect = sizeof(T) == 8 ? (T)A.aspect_d : (T)A.aspect_f;
+    const bool want_rgb = A.rgba != nullptr;
+    const bool want_nu = want_rgb || A.nu != nullptr;
+    const bool fast_ok = A.fast_ok != 0;
+    const uint32_t refill_at = A.pool_refill_at;
+    const uint32_t span = (uint32_t)(max_iter - b0);         /* updates a survivor still has to run */
+    (void)inv_w; (void)aspect; (void)resx;
+
+    WaveRing<T, NF>* ring = &rings[threadIdx.x >> 6];
+    uint32_t rhead = 0, rtail = 0;                           /* wave-uniform record counters */
+
+    WaveQueue q;
+    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
+    q.set_probes(A.q.flags);
+
+    uint64_t diag_t0 = 0;
+    uint32_t diag_items = 0, diag_claims = 0, diag_dry = 0;
+    if (A.diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
+
+    /* pool state, per lane */
+    uint32_t pixel = kInvalidPixel;      /* kInvalidPixel: lane is free */
+    uint32_t fin = 0;                    /* 1: finished, waiting to be shaded and stored */
+    Orbit<T> o;
+    o.X = o.Yd = o.cx = o.cyd = o.x2 = o.y2d = T(0);
+    uint32_t deadline = 0;
+    int esc_i = 0;
+    T esc_r2 = T(0);
+    T refX = __builtin_nan(""), refYd = __builtin_nan("");
+    uint32_t cyc = 0;
+    /* pool state, wave-uniform */
+    uint32_t next_snap = 0;
+    uint32_t snap_window = A.period_window, snap_closed = 1u;
+    const uint32_t snap_cap = A.period_window > (((uint32_t)A.max_iter >> 7) << 4) ? A.period_window : (((uint32_t)A.max_iter >> 7) << 4);
+    uint32_t wclock = 0, next_deadline = 0;
+    bool have_running = false;
+    uint32_t res_next = 0, res_end = 0, res_shard = 0;       /* reserve: shard-local sub-tile indices [res_next, res_end) */
+    bool dry = false, fast = false;
+
+    for (;;) {
+        /* ---- retire: shade and store the finished lanes ---- */
+        if (__builtin_amdgcn_ballot_w64(fin != 0u) != 0ull) {
+            if (fin != 0u) {
+                T nu;
+                float rgb[3];
+                shade<T, FRACTAL>(A, S, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
+                if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
+                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
+                if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+                if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = nu;
+                if (A.iter) A.iter[pixel] = esc_i;
+                pixel = kInvalidPixel;
+                fin = 0u;
+            }
+        }
+        const uint64_t freem = __builtin_amdgcn_ballot_w64(pixel == kInvalidPixel);
+        const uint32_t nfree = (uint32_t)__builtin_popcountll(freem);
+
+        /* ---- tile stage: until the ring can fill the free lanes (or the queue is dry) ---- */
+        while (!dry && rtail - rhead < nfree) {
+            if (res_next == res_end) {
+                uint32_t begin, count;
+                if (!q.next(begin, count, res_shard)) {
+                    dry = true;
+                    diag_dry = A.diag ? (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0) : 0u;
+                    break;
+                }
+                res_next = begin; res_end = begin + count;
+                ++diag_claims;
+                diag_items += count;
+            }
+            const uint32_t j = res_next++;
+            const uint32_t blk = (j / kShardBlock) * kShards + res_shard;
+            if (blk >= A.q.n_blk) continue;
+            const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
+            if (sid >= A.q.n_items) continue;
+            const uint32_t sty = A.q.nsx_shift >= 0 ? sid >> A.q.nsx_shift : sid / A.q.nsx;
+            const uint32_t stx = sid - sty * A.q.nsx;
+            const int px = (int)stx * FPW + lx;
+            const int lrow = (int)sty * FPH + ly;
+            const bool inside = px < W && lrow < A.rows_local;
+            int py = lrow;
+            if (A.nparts != 1) {
+                const int strip = lrow / A.rows_per_strip;
+                py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
+            }
+            const uint64_t outside_mask = __builtin_amdgcn_ballot_w64(!inside);
+            const uint32_t tpixel = (uint32_t)lrow * (uint32_t)W + (uint32_t)px;
+
+            Orbit<T> t;
+            if constexpr (FRACTAL == 0) {
+                T uvx, uvy;                                   /* shaders/mandelbrot.comp:149-151 */
+                if (A.exact_div_ok) {
+                    uvx = div_by<T>((T)px - T(0.5) * resx, resy, inv_h);
+                    uvy = div_by<T>((T)py - T(0.5) * resy, resy, inv_h);
+                } else {
+                    cold_path();
+                    uvx = ((T)px - T(0.5) * resx) / resy;
+                    uvy = ((T)py - T(0.5) * resy) / resy;
+                }
+                const T cx = center_x + uvx * zoom;
+                const T cy = center_y + uvy * zoom;
+                t.X = T(0); t.Yd = T(0); t.x2 = T(0); t.y2d = T(0);
+                t.cx = inside ? cx : T(0);
+                t.cyd = inside ? T(2) * cy : T(0);
+            } else {
+                T uvx, uvy;                                   /* shaders/julia.comp:325, :221-225; burning_ship.comp:393, :322-325 */
+                if (A.exact_div_ok) {
+                    uvx = div_by<T>((T)px, resx, inv_w);
+                    uvy = div_by<T>((T)py, resy, inv_h);
+                } else {
+                    cold_path();
+                    uvx = (T)px / resx; uvy = (T)py / resy;
+                }
+                const T z0x = center_x + (uvx - T(0.5)) * zoom * aspect;
+                const T z0y = center_y + (uvy - T(0.5)) * zoom;
+                if constexpr (FRACTAL == 1) {
+                    t.X = inside ? z0x : T(0);
+                    t.Yd = inside ? T(2) * z0y : T(0);
+                    t.cx = inside ? (T)S.julia_cx : T(0);
+                    t.cyd = inside ? T(2) * (T)S.julia_cy : T(0);
+                } else {
+                    t.X = T(0); t.Yd = T(0);
+                    t.cx = inside ? z0x : T(0);
+                    t.cyd = inside ? T(2) * z0y : T(0);
+                }
+                t.x2 = t.X * t.X;
+                t.y2d = t.Yd * t.Yd;
+            }
+            int it;
+            T r2;
+            escape_run<T, ABS, false>(t, B2, 0, b0, fast_ok, false, outside_mask, it, r2);
+            const bool alive = inside && it >= b0;
+            {   /* survivors -> the wave's ring */
+                const uint64_t m = __builtin_amdgcn_ballot_w64(alive);
+                if (m != 0ull) {
+                    if (alive) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        const uint32_t slot = (rtail + rank) & (kRingSlots - 1);
+                        ring->pix[slot] = tpixel;
+                        ring->f[0][slot] = t.X;
+                        ring->f[1][slot] = t.Yd;
+                        if constexpr (NF == 4) { ring->f[2][slot] = t.cx; ring->f[3][slot] = t.cyd; }
+                    }
+                    rtail += (uint32_t)__builtin_popcountll(m);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (inside && !alive) {
+                T nu;
+                float rgb[3];
+                shade<T, FRACTAL>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
+                if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
+                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
+                if (A.rgba) A.rgba[tpixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+                if (A.nu) reinterpret_cast<T*>(A.nu)[tpixel] = nu;
+                if (A.iter) A.iter[tpixel] = it;
+            }
+        }
+
+        /* ---- refill the free lanes from the ring ---- */
+        {
+            const uint32_t avail = rtail - rhead;
+            const uint32_t n = nfree < avail ? nfree : avail;
+            if (n != 0u) {
+                __builtin_amdgcn_wave_barrier();
+                if (pixel == kInvalidPixel) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freem, 0u));
+                    if (rank < n) {
+                        const uint32_t slot = (rhead + rank) & (kRingSlots - 1);
+                        pixel = ring->pix[slot];
+                        o.X = ring->f[0][slot];
+                        o.Yd = ring->f[1][slot];
+                        if constexpr (NF == 4) { o.cx = ring->f[2][slot]; o.cyd = ring->f[3][slot]; }
+                        else { o.cx = (T)S.julia_cx; o.cyd = T(2) * (T)S.julia_cy; }
+                        o.x2 = o.X * o.X;
+                        o.y2d = o.Yd * o.Yd;
+                        deadline = wclock + span;
+                        if constexpr (PERIOD) { refX = __builtin_nan(""); refYd = refX; cyc = 0u; }
+                    }
+                }
+                rhead += n;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        const uint64_t active = __builtin_amdgcn_ballot_w64(pixel != kInvalidPixel);
+        if (active == 0ull) break;                           /* queue dry, ring empty, every lane retired */
+        const uint32_t nactive = (uint32_t)__builtin_popcountll(active);
+        const bool last_lap = dry && rtail == rhead;         /* nothing left to refill from: run the rest out */
+        if (last_lap) __builtin_amdgcn_s_setprio(3);
+        /* refilled lanes get the LATEST deadline (wclock + span): the earliest one only changes when it is reached */
+        if (!have_running) { next_deadline = wclock + span; have_running = true; }
+
+        /* ---- iterate until `goal` lanes have finished ---- */
+        const uint32_t goal = (last_lap || refill_at > nactive) ? nactive : refill_at;
+        uint32_t newly = 0;
+        auto reach_deadline = [&](bool at_or_past) {
+            const bool running = pixel != kInvalidPixel && fin == 0u;
+            const bool hit = running && (at_or_past ? (int32_t)(wclock - deadline) >= 0 : deadline == wclock);
+            if (hit) {
+                esc_i = max_iter; esc_r2 = T(0); fin = 1u;
+                o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+            }
+            newly += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+            const uint32_t rel = wave_min_u32<T>((running && !hit) ? deadline - wclock : 0xFFFFFFFFu);
+            have_running = rel != 0xFFFFFFFFu;
+            next_deadline = wclock + (have_running ? rel : span);
+        };
+        auto close_cycles = [&]() {                          /* see pool_kernel */
+            const bool running = pixel != kInvalidPixel && fin == 0u;
+            const bool hit = running && cyc != 0u;
+            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+                if (hit) {
+                    esc_i = max_iter; esc_r2 = T(0); fin = 1u; cyc = 0u;
+                    o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                }
+                const uint32_t nhit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+                newly += nhit;
+                snap_closed += nhit;
+            }
+            if ((int32_t)(wclock - next_snap) >= 0) {
+                refX = o.X; refYd = o.Yd;
+                if (snap_closed == 0u && snap_window < snap_cap) snap_window <<= 1;
+                snap_closed = 0u;
+                next_snap = wclock + snap_window;
+            }
+        };
+        uint32_t clean = 0, streak = 0;
+        while (newly < goal) {
+            if (fast) {
+                const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
+                const uint32_t reps = streak >= 6u ? 4u : (streak >= 2u ? 2u : 1u);
+                uint32_t seen = 0u;
+                for (uint32_t rep = 0; rep < reps; ++rep) {
+#pragma unroll
+                    for (int k = 0; k < kFastBlock; ++k) orbit_step<T, ABS>(o);
+                    if constexpr (PERIOD) seen |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
+                }
+                if (__builtin_amdgcn_ballot_w64(!(orbit_r2x4(o) <= B2x4)) == 0ull) {
+                    wclock += reps * (uint32_t)kFastBlock;
+                    ++streak;
+                    if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
+                    if constexpr (PERIOD) { cyc |= seen; close_cycles(); }
+                    continue;
+                }
+                o.X = sX; o.Yd = sYd; o.x2 = sx2; o.y2d = sy2d;
+                fast = false;
+                streak = 0;
+            }
+            uint32_t n = next_deadline - wclock;
+            if (n > (uint32_t)kFastBlock) n = (uint32_t)kFastBlock;
+            uint32_t k = 0;
+            bool escaped = false;
+            do {
+                orbit_step<T, ABS>(o);
+                const T r2x4 = orbit_r2x4(o);
+                const bool e = r2x4 > B2x4;
+                const uint64_t em = __builtin_amdgcn_ballot_w64(e);
+                ++k;
+                if (em != 0ull) {
+                    if (e) {
+                        esc_i = (int)(wclock + k - 1u - (deadline - (uint32_t)max_iter));
+                        esc_r2 = T(0.25) * r2x4;
+                        fin = 1u;
+                        o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                    }
+                    newly += (uint32_t)__builtin_popcountll(em);
+                    escaped = true;
+                    if (newly >= goal) n = k;
+                }
+            } while (k < n);
+            wclock += k;
+            clean = escaped ? 0u : clean + k;
+            if (wclock == next_deadline) reach_deadline(false);
+            if constexpr (PERIOD) {
+                cyc |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
+                close_cycles();
+            }
+            if (clean >= (uint32_t)kFastBlock) { fast = fast_ok; clean = 0; }
+        }
+    }
+    if (A.diag && lane == 0) {
+        const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+        uint64_t* d = A.diag + (size_t)wave_id * 4;
+        d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = diag_items;
+        d[3] = (uint64_t)diag_claims | ((uint64_t)diag_dry << 32);
+    }
+}
+
 /* ---- Deep_Zoom: the reference's perturbation shader ------------------------------------------------
  * shaders/test_deep_zoom.comp restated operation for operation (fp32, float-float centre/zoom, explicit
  * fma in dd_mul_sf as the shader writes it), quirks included -- see DESIGN.md.  The reference orbit

@@ -226,7 +226,10 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "shift_bias"         signed change of log2 of the guided-run divisor
  *   "pool"               2 = lane-pool kernel (lanes are refilled with the next pixel as they finish),
  *                        1 = off, 0 = automatic;  "pool_refill_at" = idle lanes that trigger a refill
- *   "staging"            3 = tile pass for the first "stage_first" iterations + ONE lane-pool pass over the
+ *   "staging"            4 = FUSED: tile stage and lane pool in ONE persistent launch -- a wave maps sub-tiles, runs their
+ *                        first "stage_first" iterations, keeps the survivors in its own LDS ring and refills its 64
+ *                        persistent lanes from it (no survivor stream in HBM; 8x8 sub-tiles only, else 3);
+ *                        3 = tile pass for the first "stage_first" iterations + ONE lane-pool pass over the
  *                        compacted survivors to max_iter, 2 = tile pass + block stream passes, 1 = single pass,
  *                        0 = automatic: 3 where it applies (no SSAA, no trap/stripe effects) and pays off --
  *                        max_iterations >= 768, or >= 384 on frames above 2^23 pixels; below that one pass whose

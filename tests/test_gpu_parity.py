@@ -49,6 +49,7 @@ def gpu_render(fr, renderer, p, W, H, shard=None, host=False):
         rgba = torch.full((rows, W, 4), -7.0, dtype=torch.float32, device=dev)
         nu = torch.full((rows, W), -7.0, dtype=torch.float64 if p.precision == 1 else torch.float32, device=dev)
         it = torch.full((rows, W), -7, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()        # the fills run on torch's stream, the render on the context's own (non-blocking) one
     renderer.render(to_state(fr, p), W, H, fractal_type=fr.FractalType(p.fractal), precision=prec,
                     post_chain=bool(p.post_chain), rgba=rgba, nu=nu, iter=it, shard=shard)
     if host:
@@ -344,7 +345,7 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
             for k, v in kw.items():
                 renderer.set_option(k, v)
             cur = gpu_render(fr, renderer, p, 200, 120)
-            assert (renderer.last_stages() > 1) == (kw.get("staging", 3) in (2, 3))
+            assert (renderer.last_stages() > 1) == (kw.get("staging", 3) in (2, 3, 4))
             for a, b in zip(base, cur):
                 assert np.array_equal(a, b), kw
             for k in opts:
@@ -418,7 +419,7 @@ def test_staged_equals_single_pass(fr, renderer, oracle, name):
         assert renderer.last_stages() == 1
     finally:
         renderer.set_option("staging", 0)
-    for mode in (2, 3, 0):                 # 2: block stream passes, 3: one lane-pool pass over the survivors
+    for mode in (2, 3, 4, 0):              # 2: block stream passes, 3: one lane-pool pass over the survivors, 4: fused launch
         try:
             renderer.set_option("staging", mode)
             staged = gpu_render(fr, renderer, p, W, H)
@@ -426,9 +427,67 @@ def test_staged_equals_single_pass(fr, renderer, oracle, name):
         finally:
             renderer.set_option("staging", 0)
         # automatic (0): two passes from max_iter 768 on (384 on frames above 4K), else one; forced: from 2 budgets on
-        assert n > 1 or p.max_iterations < (768 if mode == 0 else 64)
+        assert n > 1 or p.max_iterations < (768 if mode == 0 else 64), (mode, n)
         for a, b in zip(staged, single):
             assert np.array_equal(a, b), mode
+
+
+FUSED_CASES = sorted(n for n, (p, _, _) in CASES.items() if p.fractal in (0, 1, 2) and p.aa <= 1 and not needs_effects(p)
+                     and p.max_iterations >= 64)
+
+
+@pytest.mark.parametrize("name", FUSED_CASES)
+def test_fused_launch_matches_oracle_and_the_two_pass_schedule(fr, renderer, oracle, name):
+    """The fused launch ("staging" = 4: tile stage and lane pool in one persistent kernel, survivors handed over inside
+    the wave through its LDS ring) against the oracle, and bitwise
+    against the two-launch schedule and the single pass -- on the case's own frame and on one large enough that rings
+    wrap, reserves run dry at different times and lanes are refilled many times."""
+    p, W0, H0 = CASES[name]
+    for W, H in ((W0, H0), (333, 207)):
+        planes = {}
+        for mode in (1, 3, 4):
+            try:
+                renderer.set_option("staging", mode)
+                planes[mode] = gpu_render(fr, renderer, p, W, H)
+                assert renderer.last_stages() == (1 if mode == 1 else 2)
+            finally:
+                renderer.set_option("staging", 0)
+        for a, b, c in zip(planes[1], planes[3], planes[4]):
+            assert np.array_equal(a, c) and np.array_equal(b, c)
+        ref = oracle.render(p, W, H)
+        check_against(p, ref.iter, ref.nu, ref.rgba, *planes[4])
+
+
+def test_fused_launch_under_every_geometry(fr, renderer, oracle):
+    """Queue geometry, refill threshold, tile-stage budget, cycle closing and row-strip shards must not change a pixel of
+    the fused launch."""
+    for name in ("seahorse_0008_f64", "c3_julia_f32_centre0", "ship_f64_ragged_mi2048", "reset_view_f64"):
+        p, _, _ = CASES[name]
+        W, H = 280, 168
+        try:
+            renderer.set_option("staging", 3)
+            base = gpu_render(fr, renderer, p, W, H)
+            base_sh = gpu_render(fr, renderer, p, W, H, shard=fr.Shard(2, 3, 8))
+            renderer.set_option("staging", 4)
+            for kw in (dict(), dict(workgroups_per_cu=1), dict(workgroups_per_cu=8, run_max=1), dict(run_max=64, run_min=16),
+                       dict(pool_refill_at=1), dict(pool_refill_at=64), dict(stage_first=16), dict(stage_first=48, pool_refill_at=7),
+                       dict(probes=1), dict(probes=3, run_max=2), dict(periodicity=1), dict(periodicity=16, pool_refill_at=3),
+                       dict(periodicity=4096), dict(shift_bias=-4), dict(shift_bias=6)):
+                for k, v in kw.items():
+                    renderer.set_option(k, v)
+                cur = gpu_render(fr, renderer, p, W, H)
+                assert renderer.last_stages() == 2
+                for a, b in zip(base, cur):
+                    assert np.array_equal(a, b), (name, kw)
+                part = gpu_render(fr, renderer, p, W, H, shard=fr.Shard(2, 3, 8))
+                for a, b in zip(base_sh, part):
+                    assert np.array_equal(a, b), (name, kw)
+                for k in kw:
+                    renderer.set_option(k, 0)
+        finally:
+            for k in ("staging", "workgroups_per_cu", "run_max", "run_min", "pool_refill_at", "stage_first", "probes",
+                      "periodicity", "shift_bias"):
+                renderer.set_option(k, 0)
 
 
 def test_export_rgb8(fr, renderer, oracle):
@@ -636,6 +695,7 @@ def test_c4_full_size(fr, renderer, oracle):
                 renderer.set_option(k, v)
             for t in other:
                 t.fill_(-3)
+            torch.cuda.synchronize()     # torch's stream and the context's stream are not ordered with each other
             renderer.render(st, W, H, rgba=other[0], nu=other[1], iter=other[2])
             for a, b in zip(base, other):
                 assert torch.equal(a, b), opts
@@ -682,6 +742,7 @@ def test_c5_full_size_row_bands(fr, renderer, oracle, golden):
         assert renderer.last_stages() == 2
         _band_check(oracle, p, W, H, whole, (0, 3000, 4096, 8188))
         banded = tuple(torch.full_like(t, -5) for t in whole)
+        torch.cuda.synchronize()
         R = H // 8
         for rank in range(8):
             band = (rank + frame) % 8                                   # FrameExchange: rank r renders band (r + j) mod N
@@ -1140,6 +1201,7 @@ def test_overflow_of_a_survivor_stream_is_reported_not_swallowed(fr, oracle):
         st = fr.FractalState(max_iterations=1024, zoom=1.5)               # 60 % interior: most pixels survive the tile pass
         W, H = 512, 384
         nu = torch.empty((H, W), dtype=torch.float64, device="cuda:0")
+        r.set_option("staging", 3)                                        # the two-launch schedule: the one with a stream in HBM
         r.render(st, W, H, nu=nu)
         good = nu.clone()
         r.set_option("debug_region_blocks", 1)                            # 8 regions x 1 block = 512 records
@@ -1193,6 +1255,7 @@ def test_reserved_async_render_is_launch_only(fr, oracle):
             for _ in range(3):
                 nu.fill_(-1.0)
                 rgba.fill_(-1.0)
+                torch.cuda.synchronize()
                 g.replay()
                 torch.cuda.synchronize()
                 assert torch.equal(nu, want_nu) and torch.equal(rgba, want_rgba)
