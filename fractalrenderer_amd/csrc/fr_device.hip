@@ -59,6 +59,7 @@ struct fr_ctx {
     void* scratch;              /* device staging for FR_MEM_HOST outputs */
     size_t scratch_bytes;
     uint32_t debug_region_blocks; /* tests only: cap the capacity of a survivor-stream region, to provoke an overflow */
+    double2* log2_tab;          /* device copy of the log2 table of the fp64 smooth-count epilogue (log2_tab()) */
     uint32_t* overflow_host;    /* pinned, device-mapped word: a survivor stream ran out of blocks (see StreamRef::overflow) */
     uint32_t* overflow_dev;     /* the same word as the kernels address it */
     bool render_on_user_stream; /* the most recent render was enqueued on a caller's stream: ev_end orders the context's
@@ -105,6 +106,22 @@ extern "C" int fr_ctx_create(int device_ordinal, fr_ctx** out)
         return fr_set_error(FR_ERR_HIP, "context setup failed: %s", hipGetErrorString(e2));
     }
     *c->overflow_host = 0u;
+    {   /* log2 table: bin i of [0.5, 1) has midpoint m_i = 0.5 + (i + 0.5) / 256; entry = {y_i = RN(1 / m_i), -log2(y_i)}.
+         * The logarithm is taken of the ROUNDED reciprocal (in 64-bit long double), so that m = (1 + r) / y_i holds for
+         * the r the kernels compute and the table contributes no error of its own beyond its final rounding. */
+        double tab[2 * kLog2Entries];
+        for (int i = 0; i < kLog2Entries; ++i) {
+            const double m = 0.5 + ((double)i + 0.5) / (2.0 * kLog2Entries);
+            const double y = 1.0 / m;
+            tab[2 * i] = y;
+            tab[2 * i + 1] = (double)(-log2l((long double)y));
+        }
+        if ((e2 = hipMalloc((void**)&c->log2_tab, sizeof(tab))) != hipSuccess ||
+            (e2 = hipMemcpy(c->log2_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess) {
+            free(c);
+            return fr_set_error(FR_ERR_HIP, "context setup failed: %s", hipGetErrorString(e2));
+        }
+    }
     *out = c;
     return FR_OK;
 }
@@ -117,6 +134,7 @@ extern "C" void fr_ctx_destroy(fr_ctx* c)
     if (c->scratch) (void)hipFree(c->scratch);
     (void)hipFree(c->d_ctrl);
     if (c->overflow_host) (void)hipHostFree(c->overflow_host);
+    if (c->log2_tab) (void)hipFree(c->log2_tab);
     for (int k = 0; k < 2; ++k) if (c->stream_buf[k]) (void)hipFree(c->stream_buf[k]);
     if (c->frame_buf) (void)hipFree(c->frame_buf);
     if (c->orbit_host) (void)hipHostFree(c->orbit_host);
@@ -354,6 +372,13 @@ static int check_overflow(fr_ctx* c)
                                          "incomplete (internal sizing error, please report the frame geometry)");
 }
 
+/* zero the queue heads and stream counters of the next render (a kernel, not a memset node: see clear_words_kernel) */
+static hipError_t clear_control_block(fr_ctx* c, hipStream_t stream)
+{
+    hipLaunchKernelGGL(clear_words_kernel, dim3(4), dim3(kBlockThreads), 0, stream, c->d_ctrl, (uint32_t)kCtrlWords);
+    return hipGetLastError();
+}
+
 /* Work on the context's own stream (exports, colorize without a stream argument) must see the planes of a render that
  * was enqueued on a CALLER's stream: ev_end was recorded there behind the last launch. */
 static hipError_t order_after_last_render(fr_ctx* c, hipStream_t s)
@@ -425,7 +450,7 @@ static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t
     c->last_grid = grid;
     c->last_stages = 1;
 
-    FR_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, kCtrlWords * sizeof(uint32_t), stream));
+    FR_HIP_TRY(clear_control_block(c, stream));
     FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
     hipLaunchKernelGGL((deep_zoom_kernel<3>), dim3(grid), dim3(kBlockThreads), 0, stream, a);
     hipError_t e = hipGetLastError();
@@ -633,6 +658,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.part = (int32_t)norm.part; a.nparts = (int32_t)norm.nparts; a.rows_per_strip = (int32_t)norm.rows_per_strip;
     a.rgba = reinterpret_cast<float4*>(rgba);
     a.nu = nu; a.iter = iter;
+    a.log2_tab = c->log2_tab;
 
     /* escape is absorbing (see escape_run): bailout^2 in [4.5, 1e12], and for Julia |c| <= bailout;
      * Mandelbrot lanes with |c| > bailout retire at i = 0 inside the first, tested block */
@@ -694,7 +720,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     }
     if (reserve_only) return FR_OK;
 
-    FR_HIP_TRY(hipMemsetAsync(c->d_ctrl, 0, kCtrlWords * sizeof(uint32_t), stream));
+    FR_HIP_TRY(clear_control_block(c, stream));
     FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
 
     /* ---- tile pass ---------------------------------------------------------------------------------- */

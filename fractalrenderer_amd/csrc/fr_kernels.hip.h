@@ -126,6 +126,7 @@ struct LaunchArgs {
     void* nu;
     int32_t* iter;
     QueueArgs q;
+    const double2* log2_tab;     /* kLog2Entries x {1/m_i, log2 m_i}: see log2_tab() (built on the host, staged into LDS) */
     uint64_t* diag;              /* optional: 4 words per wave (t_start, t_end, items, dequeues) */
     fr_palette_table pal;
 };
@@ -207,6 +208,49 @@ __device__ __forceinline__ double log2_pos(double x)
 }
 /* fp32: the hardware log2 (v_log_f32, ~1 ulp), which is also what a GLSL log() lowers to */
 __device__ __forceinline__ float log2_pos(float x) { return __builtin_amdgcn_logf(x); }
+
+/* The same function from a table in LDS: x = 2^e m, m in [0.5, 1); the top 7 mantissa bits select a bin whose midpoint
+ * m_i has y_i = RN(1/m_i) and L_i = -log2(y_i) (to 64 bits on the host) in the table; r = m y_i - 1 (one fma, |r| < 2^-8)
+ * and log2 x = (e + L_i) + log2(1 + r), the last term a degree-5 polynomial (truncation r^6 / (6 ln 2) < 9e-16).
+ * 10 fp64-rate instructions + one ds_read_b128 against 33 for the series above: the two logs of the smooth count are
+ * 24 of every 26 fp64 instructions the epilogue of a pixel costs.  Error < 2e-15 absolute: nu moves by ~1e-15. */
+constexpr int kLog2Entries = 128;
+__device__ __forceinline__ double log2_tab(const double2* __restrict__ tab, double x)
+{
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const double m = __builtin_amdgcn_frexp_mant(x);                        /* [0.5, 1) */
+    const uint32_t hi = (uint32_t)((uint64_t)__double_as_longlong(m) >> 32);
+    const double2 en = tab[(hi >> 13) & (uint32_t)(kLog2Entries - 1)];      /* top 7 of the 52 mantissa bits */
+    const double r = __builtin_fma(m, en.x, -1.0);
+    double p = 0.28853900817779268;                                         /* +1/(5 ln 2) */
+    p = __builtin_fma(p, r, -0.36067376022224085);                          /* -1/(4 ln 2) */
+    p = __builtin_fma(p, r, 0.48089834696298783);                           /* +1/(3 ln 2) */
+    p = __builtin_fma(p, r, -0.72134752044448170);                          /* -1/(2 ln 2) */
+    p = __builtin_fma(p, r, 1.4426950408889634);                            /* +1/ln 2     */
+    return __builtin_fma(p, r, (double)e + en.y);
+}
+/* what a kernel hands to shade(): the staged table (fp64) or nothing (fp32: hardware log2) */
+template <typename T> struct LogTab;
+template <> struct LogTab<double> {
+    const double2* tab;
+    __device__ __forceinline__ double log2(double x) const { return log2_tab(tab, x); }
+};
+template <> struct LogTab<float> {
+    __device__ __forceinline__ float log2(float x) const { return log2_pos(x); }
+};
+/* stage the table into the workgroup's LDS (fp64 kernels): 128 x 16 B, one half entry per thread */
+template <typename T>
+__device__ __forceinline__ LogTab<T> stage_log2(double2* lds, const LaunchArgs& A)
+{
+    if constexpr (sizeof(T) == 8) {
+        reinterpret_cast<double*>(lds)[threadIdx.x] = reinterpret_cast<const double*>(A.log2_tab)[threadIdx.x];
+        __syncthreads();
+        return LogTab<double>{lds};
+    } else {
+        (void)lds; (void)A;
+        return LogTab<float>{};
+    }
+}
 
 /* Marks a rarely taken branch: the optimiser otherwise evaluates BOTH sides of a cheap-looking if/else and
  * selects (found in the ISA: the 12-instruction IEEE fp64 divide ran next to its 3-op replacement for every
@@ -325,7 +369,7 @@ __device__ __forceinline__ void colour_of(const LaunchArgs& A, const LdsBlock& S
  * index, it >= max_iter for a sample that never escaped.
  * Mandelbrot: shaders/mandelbrot.comp:172-190; Julia: shaders/julia.comp:237-248. */
 template <typename T, int FRACTAL>
-__device__ __forceinline__ void shade(const LaunchArgs& A, const LdsBlock& S, const int it, const T r2,
+__device__ __forceinline__ void shade(const LaunchArgs& A, const LdsBlock& S, const LogTab<T>& lg, const int it, const T r2,
                                       const bool want_nu, const bool want_rgb, T& nu, float rgb[3])
 {
     const int max_iter = S.max_iter;
@@ -336,7 +380,7 @@ __device__ __forceinline__ void shade(const LaunchArgs& A, const LdsBlock& S, co
     if (it < max_iter) {
         if constexpr (FRACTAL == 0) {                                 /* :173-177: mu = log2(log2|z|) */
             if (!A.lib_log) {
-                nu = (T)it + T(1) - log2_pos(T(0.5) * log2_pos(r2));
+                nu = (T)it + T(1) - lg.log2(T(0.5) * lg.log2(r2));
             } else {
                 const T log_zn = Real<T>::log(r2) / T(2);
                 nu = (T)it + T(1) - Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
@@ -344,7 +388,7 @@ __device__ __forceinline__ void shade(const LaunchArgs& A, const LdsBlock& S, co
         } else {                                                      /* julia.comp:237-248 */
             /* log(log(r2)/log(B))/log 2 == log2(log2(r2) / log2(B)) */
             if (!A.lib_log)
-                nu = (T)it + T(1) - log2_pos(log2_pos(r2) * (T)A.inv_log2_bailout);
+                nu = (T)it + T(1) - lg.log2(lg.log2(r2) * (T)A.inv_log2_bailout);
             else
                 nu = (T)it + T(1) - Real<T>::log(Real<T>::log(r2) / (T)S.log_bailout) / Real<T>::ln2();
         }
@@ -374,6 +418,16 @@ colorize_kernel(const LaunchArgs A, const T* __restrict__ nu_in, float4* __restr
             post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
         rgba[i] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
     }
+}
+
+/* ---- control block ---------------------------------------------------------------------------------------------
+ * Queue heads and stream counters of a render are zeroed by this kernel, not by hipMemsetAsync: a memset node captured
+ * into a HIP graph did its work on the first replay only (ROCm 7.2: the second replay found the heads where the first
+ * had left them and rendered nothing), and fr_render_shard_async is meant to be capturable. */
+__global__ void __launch_bounds__(kBlockThreads)
+clear_words_kernel(uint32_t* __restrict__ p, const uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += gridDim.x * kBlockThreads) p[i] = 0u;
 }
 
 /* ---- XCD id ------------------------------------------------------------------------------ */
@@ -874,6 +928,8 @@ tile_kernel(const LaunchArgs A)
     __shared__ LdsBlock S;
     __shared__ WaveRing<T, NF> rings[EFFECTS ? 1 : kWavesPerBlock];
     stage_constants(S, A);
+    __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
+    const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 
     const int lane = threadIdx.x & (kWave - 1);
     const int lx = lane & (FPW - 1);
@@ -976,7 +1032,7 @@ tile_kernel(const LaunchArgs A)
                             const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
                             writer.append(alive, pixel, (uint32_t)i1, rec);
                         }
-                        if (!alive) shade<T, 0>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
+                        if (!alive) shade<T, 0>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                     } else {
                         T ezx, ezy, min_trap;
                         Orbit<T> o;
@@ -1047,7 +1103,7 @@ tile_kernel(const LaunchArgs A)
                                                    outside_mask, A.trap_enabled != 0, (T)S.trap_radius,
                                                    stripes, (T)S.stripe_density, it, r2, min_dist, stripe_sum);
                         if (it < max_iter) {
-                            shade<T, 2>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
+                            shade<T, 2>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                             if (A.trap_enabled && want_rgb) {                 /* burning_ship.comp:302-306 */
                                 const float infl = 1.0f - clamp01((float)min_dist * 2.0f);
                                 float tc[3];
@@ -1093,7 +1149,7 @@ tile_kernel(const LaunchArgs A)
                             for (int k = 0; k < NF; ++k) rec[k] = rec4[k];
                             writer.append(alive, pixel, (uint32_t)i1, rec);
                         }
-                        if (!alive) shade<T, FRACTAL>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
+                        if (!alive) shade<T, FRACTAL>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                     }
                 }
                 if (s == 0) { first_nu = nu; first_it = it; }
@@ -1132,6 +1188,8 @@ stream_kernel(const LaunchArgs A)
     __shared__ LdsBlock S;
     __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
     stage_constants(S, A);
+    __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
+    const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const int max_iter = A.max_iter;
@@ -1208,7 +1266,7 @@ stream_kernel(const LaunchArgs A)
             if (valid && !alive) {
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
+                shade<T, FRACTAL>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
@@ -1220,6 +1278,33 @@ stream_kernel(const LaunchArgs A)
     }
     if (more) writer.finish();
     diag_write(A, lane, diag_t0, diag_items, diag_claims);
+}
+
+/* A dirty unchecked stretch (some lane of `badm` escaped inside it) used to be rolled back as a whole and replayed with
+ * per-update tests: the kmax updates of every OTHER lane were thrown away and run again.  Only the escaped lanes need the
+ * replay -- to learn the index and |z|^2 of their escaping update; everybody else's state after the stretch is already
+ * right (nothing of it depends on another lane).  So the snapshot is replayed in scratch registers, tested, until every
+ * lane of badm has been located (the same operations in the same order: bit-identical to the stretch itself, and a lane
+ * that is beyond the bailout at the end has crossed it at a finite update, escape being absorbing), and the stretch
+ * counts.  k: offset of the escaping update inside the stretch (lanes of badm only), r2x4: 4 |z|^2 there. */
+template <typename T, bool ABS>
+__device__ __forceinline__ void locate_escapes(T sX, T sYd, T sx2, T sy2d, const T cx, const T cyd, const T B2x4,
+                                               const bool bad, uint64_t pending, const uint32_t kmax,
+                                               uint32_t& esc_k, T& esc_r2x4)
+{
+    Orbit<T> t;
+    t.X = sX; t.Yd = sYd; t.x2 = sx2; t.y2d = sy2d; t.cx = cx; t.cyd = cyd;
+    bool open = bad;
+    esc_k = 0u; esc_r2x4 = T(0);
+    uint32_t k = 0;
+    do {
+        orbit_step<T, ABS>(t);
+        const T r = orbit_r2x4(t);
+        const bool e = open && r > B2x4;
+        if (e) { esc_k = k; esc_r2x4 = r; open = false; }
+        pending &= ~__builtin_amdgcn_ballot_w64(e);
+        ++k;
+    } while (pending != 0ull && k < kmax);
 }
 
 /* ---- lane pool ------------------------------------------------------------------------------------
@@ -1265,6 +1350,8 @@ pool_kernel(const LaunchArgs A)
 
     __shared__ LdsBlock S;
     stage_constants(S, A);
+    __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
+    const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     /* integers straight from the kernel arguments (wave-uniform SGPRs); through LDS they would be VGPR values
@@ -1324,7 +1411,7 @@ pool_kernel(const LaunchArgs A)
             if (fin != 0u) {
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(A, S, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
+                shade<T, FRACTAL>(A, S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
@@ -1493,6 +1580,7 @@ pool_kernel(const LaunchArgs A)
         };
         uint32_t clean = 0;            /* tested updates since the last escape */
         uint32_t streak = 0;           /* clean unchecked blocks in a row */
+        uint32_t dirty_run = 0;        /* dirty unchecked stretches in a row */
         while (newly < goal) {
             if (fast) {
                 const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
@@ -1505,18 +1593,35 @@ pool_kernel(const LaunchArgs A)
                     for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
                     if constexpr (PERIOD) seen |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
                 }
-                if (__builtin_amdgcn_ballot_w64(!(orbit_r2x4(o) <= B2x4)) == 0ull) {
-                    wclock += reps * (uint32_t)kFastBlock;
+                const bool bad = !(orbit_r2x4(o) <= B2x4);
+                const uint64_t badm = __builtin_amdgcn_ballot_w64(bad);
+                if (badm != 0ull) {
+                    /* dirty stretch: locate the escaped lanes' updates (locate_escapes), keep everybody else's progress */
+                    uint32_t ek; T er;
+                    locate_escapes<T, Form<FRACTAL>::abs_step>(sX, sYd, sx2, sy2d, o.cx, o.cyd, B2x4, bad, badm,
+                                                               reps * (uint32_t)kFastBlock, ek, er);
+                    if (bad) {
+                        /* an escape at or past the lane's deadline is no escape: the sample ran its max_iter updates */
+                        const int idx = (int)(wclock + ek - (deadline - (uint32_t)max_iter));
+                        esc_i = idx < max_iter ? idx : max_iter;
+                        esc_r2 = idx < max_iter ? T(0.25) * er : T(0);
+                        fin = 1u;
+                        o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                    }
+                    newly += (uint32_t)__builtin_popcountll(badm);
+                    streak = 0;
+                    /* escape-dense neighbourhood: per-update tests are cheaper than locating block after block */
+                    if (++dirty_run >= 2u) fast = false;
+                } else {
                     ++streak;
-                    /* clean block: lanes at or past their deadline never escaped -> interior */
-                    if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
-                    if constexpr (PERIOD) { cyc |= seen; close_cycles(); }
-                    continue;
+                    dirty_run = 0;
                 }
-                /* dirty: `seen` is dropped with the block (a lane that escaped inside it is not on a cycle) */
-                o.X = sX; o.Yd = sYd; o.x2 = sx2; o.y2d = sy2d;      /* roll back, replay tested */
-                fast = false;
-                streak = 0;
+                wclock += reps * (uint32_t)kFastBlock;
+                /* lanes at or past their deadline that are still running never escaped -> interior */
+                if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
+                /* (a lane that escaped inside the stretch is finished: close_cycles only looks at running lanes) */
+                if constexpr (PERIOD) { cyc |= seen; close_cycles(); }
+                continue;
             }
             /* tested stretch: up to the next deadline, at most one block.  The loop carries a countdown and
              * one vector-compare branch; goal and deadline are only looked at where they can change (on an
@@ -1598,6 +1703,8 @@ fused_kernel(const LaunchArgs A)
     __shared__ LdsBlock S;
     __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
     stage_constants(S, A);
+    __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
+    const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const int lx = (int)(lane & (FPW - 1)), ly = (int)(lane >> FPW_LOG2);
@@ -1653,7 +1760,7 @@ fused_kernel(const LaunchArgs A)
             if (fin != 0u) {
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(A, S, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
+                shade<T, FRACTAL>(A, S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
@@ -1759,7 +1866,7 @@ fused_kernel(const LaunchArgs A)
             if (inside && !alive) {
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(A, S, it, r2, want_nu, want_rgb, nu, rgb);
+                shade<T, FRACTAL>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[tpixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
@@ -1835,7 +1942,7 @@ fused_kernel(const LaunchArgs A)
                 next_snap = wclock + snap_window;
             }
         };
-        uint32_t clean = 0, streak = 0;
+        uint32_t clean = 0, streak = 0, dirty_run = 0;
         while (newly < goal) {
             if (fast) {
                 const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
@@ -1846,16 +1953,35 @@ fused_kernel(const LaunchArgs A)
                     for (int k = 0; k < kFastBlock; ++k) orbit_step<T, ABS>(o);
                     if constexpr (PERIOD) seen |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
                 }
-                if (__builtin_amdgcn_ballot_w64(!(orbit_r2x4(o) <= B2x4)) == 0ull) {
-                    wclock += reps * (uint32_t)kFastBlock;
+                const bool bad = !(orbit_r2x4(o) <= B2x4);
+                const uint64_t badm = __builtin_amdgcn_ballot_w64(bad);
+                if (badm != 0ull) {
+                    /* dirty stretch: locate the escaped lanes' updates (locate_escapes), keep everybody else's progress */
+                    uint32_t ek; T er;
+                    locate_escapes<T, ABS>(sX, sYd, sx2, sy2d, o.cx, o.cyd, B2x4, bad, badm,
+                                                               reps * (uint32_t)kFastBlock, ek, er);
+                    if (bad) {
+                        /* an escape at or past the lane's deadline is no escape: the sample ran its max_iter updates */
+                        const int idx = (int)(wclock + ek - (deadline - (uint32_t)max_iter));
+                        esc_i = idx < max_iter ? idx : max_iter;
+                        esc_r2 = idx < max_iter ? T(0.25) * er : T(0);
+                        fin = 1u;
+                        o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                    }
+                    newly += (uint32_t)__builtin_popcountll(badm);
+                    streak = 0;
+                    /* escape-dense neighbourhood: per-update tests are cheaper than locating block after block */
+                    if (++dirty_run >= 2u) fast = false;
+                } else {
                     ++streak;
-                    if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
-                    if constexpr (PERIOD) { cyc |= seen; close_cycles(); }
-                    continue;
+                    dirty_run = 0;
                 }
-                o.X = sX; o.Yd = sYd; o.x2 = sx2; o.y2d = sy2d;
-                fast = false;
-                streak = 0;
+                wclock += reps * (uint32_t)kFastBlock;
+                /* lanes at or past their deadline that are still running never escaped -> interior */
+                if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
+                /* (a lane that escaped inside the stretch is finished: close_cycles only looks at running lanes) */
+                if constexpr (PERIOD) { cyc |= seen; close_cycles(); }
+                continue;
             }
             uint32_t n = next_deadline - wclock;
             if (n > (uint32_t)kFastBlock) n = (uint32_t)kFastBlock;
