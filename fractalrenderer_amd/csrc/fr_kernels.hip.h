@@ -430,6 +430,25 @@ clear_words_kernel(uint32_t* __restrict__ p, const uint32_t n)
     for (uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += gridDim.x * kBlockThreads) p[i] = 0u;
 }
 
+/* ---- diagnostic build (-DFR_STAMP): where a wave's time goes ---------------------------------------------------
+ * Per wave, shader-clock cycles spent inside the marked regions, written next to the timeline words of the diag buffer
+ * (8 words per wave in this build: t0, t1, items, claims, then cycles in: dequeue, block claim, refill wait, retire/shade).
+ * Never compiled into the product library. */
+#ifdef FR_STAMP
+#define FR_STAMP_DECL uint64_t st_acc[4] = {0, 0, 0, 0}; uint64_t st_t = 0; (void)st_t;
+#define FR_STAMP_BEGIN() do { st_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define FR_STAMP_END(k) do { st_acc[k] += __builtin_amdgcn_s_memtime() - st_t; } while (0)
+#define FR_STAMP_WRITE(A, lane) do { if ((A).diag && (lane) == 0) { uint64_t* d_ = (A).diag + (size_t)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 8 + 4; \
+        d_[0] = st_acc[0]; d_[1] = st_acc[1]; d_[2] = st_acc[2]; d_[3] = st_acc[3]; } } while (0)
+constexpr int kDiagWords = 8;
+#else
+#define FR_STAMP_DECL
+#define FR_STAMP_BEGIN() do {} while (0)
+#define FR_STAMP_END(k) do {} while (0)
+#define FR_STAMP_WRITE(A, lane) do {} while (0)
+constexpr int kDiagWords = 4;
+#endif
+
 /* ---- XCD id ------------------------------------------------------------------------------ */
 __device__ __forceinline__ uint32_t xcc_id()
 {
@@ -555,6 +574,9 @@ struct RingWriter {
     uint32_t lane;
     uint32_t head, tail;          /* wave-uniform record counters */
     uint32_t home;                /* region this wave appends to (its XCD) */
+#ifdef FR_STAMP
+    uint64_t st_block = 0;        /* cycles inside take_block */
+#endif
 
     static constexpr size_t kHeaderBytes = 2 * 64 * 4;           /* pixel + iterations-done planes */
     static constexpr size_t kBlockBytes = kHeaderBytes + (size_t)NF * 64 * sizeof(T);
@@ -567,6 +589,10 @@ struct RingWriter {
      * load); a full region spills to the next one -- the 8 regions together hold 1.5x the worst case */
     __device__ __forceinline__ bool take_block(uint32_t& region, uint32_t& blk)
     {
+#ifdef FR_STAMP
+        const uint64_t st0 = __builtin_amdgcn_s_memtime();
+        struct Acc { uint64_t& a; uint64_t t0; __device__ ~Acc() { a += __builtin_amdgcn_s_memtime() - t0; } } acc_{st_block, st0};
+#endif
         for (uint32_t t = 0; t < (uint32_t)kShards; ++t) {
             region = (home + t) & (uint32_t)(kShards - 1);
             uint32_t v = 0;
@@ -905,7 +931,7 @@ __device__ __forceinline__ void diag_write(const LaunchArgs& A, uint32_t lane, u
 {
     if (A.diag && lane == 0) {      /* diagnostics: per-wave timeline (100 MHz ticks) and work counts */
         const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-        uint64_t* d = A.diag + (size_t)wave_id * 4;
+        uint64_t* d = A.diag + (size_t)wave_id * kDiagWords;
         d[0] = t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = items; d[3] = claims;
     }
 }
@@ -968,7 +994,12 @@ tile_kernel(const LaunchArgs A)
     if (A.diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
 
     uint32_t begin, count, cur_shard;
-    while (q.next(begin, count, cur_shard)) {
+    FR_STAMP_DECL
+    for (;;) {
+        FR_STAMP_BEGIN();
+        const bool got_run = q.next(begin, count, cur_shard);
+        FR_STAMP_END(0);
+        if (!got_run) break;
         ++diag_claims;
         diag_items += count;
         for (uint32_t j = begin; j < begin + count; ++j) {
@@ -1172,6 +1203,10 @@ tile_kernel(const LaunchArgs A)
     }
     if (staged) writer.finish();
     diag_write(A, (uint32_t)lane, diag_t0, diag_items, diag_claims);
+#ifdef FR_STAMP
+    st_acc[1] = writer.st_block;
+#endif
+    FR_STAMP_WRITE(A, lane);
 }
 
 /* ---- stream pass ---------------------------------------------------------------------------------
@@ -1405,8 +1440,10 @@ pool_kernel(const LaunchArgs A)
     uint32_t res_begin = 0, res_count = 0, res_shard = 0, res_next = 0;    /* reserve: run of 64-item groups, cursor in items */
     bool dry = false, fast = false;
 
+    FR_STAMP_DECL
     for (;;) {
         /* ---- retire: shade and store the finished lanes ---- */
+        FR_STAMP_BEGIN();
         if (__builtin_amdgcn_ballot_w64(fin != 0u) != 0ull) {
             if (fin != 0u) {
                 T nu;
@@ -1421,12 +1458,21 @@ pool_kernel(const LaunchArgs A)
                 fin = 0u;
             }
         }
+        FR_STAMP_END(3);
         /* ---- refill the free lanes from the reserve ---- */
+        FR_STAMP_BEGIN();
         for (;;) {
             const uint64_t freem = __builtin_amdgcn_ballot_w64(pixel == kInvalidPixel);
             if (freem == 0ull || dry) break;
             if (res_next == res_count * 64u) {
+#ifdef FR_STAMP
+                const uint64_t stq = __builtin_amdgcn_s_memtime();
+                const bool got_q = q.next(res_begin, res_count, res_shard);
+                st_acc[0] += __builtin_amdgcn_s_memtime() - stq;
+                if (!got_q) {
+#else
                 if (!q.next(res_begin, res_count, res_shard)) {
+#endif
                     dry = true;
                     /* diagnostics: when this wave found the queue dry, in 100 MHz ticks since its start (bits 32..) */
                     diag_dry = A.diag ? (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0) : 0u;
@@ -1520,6 +1566,14 @@ pool_kernel(const LaunchArgs A)
             }
             res_next += n;
         }
+#ifdef FR_STAMP
+        {   /* the records must have arrived before the clock is read: touch them */
+            const T touch = o.X + o.Yd + o.cx + o.cyd;
+            asm volatile("" :: "v"(touch));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#endif
+        FR_STAMP_END(2);
         const uint64_t active = __builtin_amdgcn_ballot_w64(pixel != kInvalidPixel);
         if (active == 0ull) break;                           /* queue dry and every lane retired */
         const uint32_t nactive = (uint32_t)__builtin_popcountll(active);
@@ -1664,10 +1718,11 @@ pool_kernel(const LaunchArgs A)
     }
     if (A.diag && lane == 0) {      /* as diag_write, with the dry time packed above the dequeue count */
         const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-        uint64_t* d = A.diag + (size_t)wave_id * 4;
+        uint64_t* d = A.diag + (size_t)wave_id * kDiagWords;
         d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = diag_items;
         d[3] = (uint64_t)diag_claims | ((uint64_t)diag_dry << 32);
     }
+    FR_STAMP_WRITE(A, lane);
 }
 
 /* ---- fused pass: tile stage + lane pool in ONE persistent launch, hand-off inside the wave -----------------------
@@ -2017,7 +2072,7 @@ fused_kernel(const LaunchArgs A)
     }
     if (A.diag && lane == 0) {
         const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-        uint64_t* d = A.diag + (size_t)wave_id * 4;
+        uint64_t* d = A.diag + (size_t)wave_id * kDiagWords;
         d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = diag_items;
         d[3] = (uint64_t)diag_claims | ((uint64_t)diag_dry << 32);
     }
