@@ -346,6 +346,10 @@ def main() -> None:
     def new_renderer():
         rr = fr.Renderer(local_rank)
         rr.set_tuning(args.wg_per_cu, args.run_max, args.shape)
+        # The library closes cycles by default ("periodicity": exact, planes byte-identical, but fewer iterations than the
+        # reference's shaders execute).  Every timed leg except the `periodicity` one runs with it OFF, so that `value`,
+        # `roofline` and `roofline_valu` are quoted on the reference's iteration count.
+        rr.set_option("periodicity", -1)
         for kv in filter(None, args.options.split(",")):
             k, v = kv.split("=")
             rr.set_option(k.strip(), int(v, 0))
@@ -395,14 +399,14 @@ def main() -> None:
         # the phase boundaries of a frame (tile-pass tail, launch gaps, pool-pass drain) with the other frame's
         # work.  NOT the headline `value`: that stays one frame at a time, so that `roofline` keeps its
         # per-launch meaning and agrees with the rocprofv3 kernel durations.
-        # Secondary, informational: the same K steps with the library's "periodicity" option on.  The lane pool
+        # Secondary, informational: the same K steps with the library's default, cycle closing ("periodicity") ON.  The lane pool
         # then retires an orbit as interior the moment it returns to an earlier state of its own (it can never
         # escape: the update is a deterministic function of (z, c)); every plane stays byte-identical
         # (tests/test_gpu_parity.py::test_periodicity_never_changes_a_pixel) but FEWER iterations are executed
         # than the reference's shaders would run, so it is NOT the headline `value` and carries no roofline.
         dt_cyc = None
         if not args.no_periodicity:
-            r.set_option("periodicity", 1)
+            r.set_option("periodicity", 0)             # the library's default
             check = torch.empty_like(rgba)
             r.render(state, W, H, fractal_type=ftype, precision=prec, rgba=check)
             cyc_identical = bool(torch.equal(check, rgba))
@@ -415,7 +419,7 @@ def main() -> None:
                 step(k)
             barrier()
             dt_cyc = time.perf_counter() - t0c
-            r.set_option("periodicity", 0)
+            r.set_option("periodicity", -1)
 
         dt_pipe = None
         if args.pipelined:
@@ -591,10 +595,11 @@ def main() -> None:
                 out["periodicity"] = {"value": round(args.steps * W * H / dt_cyc / 1e6, 2), "unit": "Mpixels/s",
                                       "ms_per_step": round(dt_cyc / args.steps * 1e3, 4),
                                       "output_identical_to_headline_run": cyc_identical,
-                                      "note": "informational: fr_ctx_set_option(\"periodicity\", 1) -- orbits that return to an "
+                                      "note": "informational: the library's DEFAULT (cycle closing on) -- orbits that return to an "
                                               "earlier state of their own are retired as interior at once (exact; planes "
                                               "byte-identical), so fewer iterations run than the reference executes; the "
-                                              "headline value above iterates every interior sample to max_iter"}
+                                              "headline value above switches it off (fr_ctx_set_option(\"periodicity\", -1)) "
+                                              "and iterates every interior sample to max_iter"}
             if dt_pipe is not None:
                 out["pipelined"] = {"frames_in_flight": 2, "value": round(args.steps * W * H / dt_pipe / 1e6, 2),
                                     "unit": "Mpixels/s", "ms_per_step": round(dt_pipe / args.steps * 1e3, 4),

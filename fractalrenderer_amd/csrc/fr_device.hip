@@ -39,7 +39,7 @@ struct fr_ctx {
     size_t stream_bytes[2];
     uint32_t tune_pool;         /* 0 = automatic (currently off), 1 = off, 2 = on: lane-pool kernel */
     uint32_t tune_pool_refill;  /* idle lanes that trigger a refill (0 = 32) */
-    uint32_t tune_periodicity;  /* 0 off; else the lane pool closes orbits that return to their own snapshot (window in iterations) */
+    int32_t tune_periodicity;   /* cycle closing: -1 off, 0 automatic (on, first window 128), else the first snapshot window in iterations */
     uint32_t tune_staging;      /* 0 = automatic (currently off), 1 = off (single pass), 2 = on */
     uint32_t tune_stage_first;  /* first budget b0 (0 = 32) */
     uint32_t tune_stage_ratio;  /* budget growth per stage (0 = 4) */
@@ -178,8 +178,8 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         if (value < 0 || value > 64) return fr_set_error(FR_ERR_INVALID_ARG, "pool_refill_at must be in [0,64]");
         c->tune_pool_refill = (uint32_t)value;
     } else if (!strcmp(name, "periodicity")) {
-        if (value < 0 || value > (1 << 20)) return fr_set_error(FR_ERR_INVALID_ARG, "periodicity must be 0 (off), 1 (on) or a snapshot window in iterations");
-        c->tune_periodicity = value == 1 ? 128u : (uint32_t)((value + 15) / 16 * 16);
+        if (value < -1 || value > (1 << 20)) return fr_set_error(FR_ERR_INVALID_ARG, "periodicity must be -1 (off), 0 (automatic: on), 1 (on) or a first snapshot window in iterations");
+        c->tune_periodicity = value <= 0 ? (int32_t)value : (value == 1 ? 128 : (int32_t)((value + 15) / 16 * 16));
     } else if (!strcmp(name, "staging")) {
         if (value < 0 || value > 4) return fr_set_error(FR_ERR_INVALID_ARG, "staging must be 0 (automatic), 1 (single pass), 2 (block stages), 3 (tile pass + lane-pool pass) or 4 (fused: one launch)");
         c->tune_staging = (uint32_t)value;
@@ -368,8 +368,19 @@ static int check_overflow(fr_ctx* c)
 {
     if (__atomic_load_n(c->overflow_host, __ATOMIC_RELAXED) == 0u) return FR_OK;
     __atomic_store_n(c->overflow_host, 0u, __ATOMIC_RELAXED);
-    return fr_set_error(FR_ERR_INTERNAL, "a survivor stream overflowed: the frame of the last render on this context is "
-                                         "incomplete (internal sizing error, please report the frame geometry)");
+    return fr_set_error(FR_ERR_INTERNAL, "a kernel reported an internal error (a survivor stream overflowed, or a lane-pool wave "
+                                         "gave up on a stretch that would not end): the frame of the last render on this context "
+                                         "is incomplete, please report the parameters");
+}
+
+/* Cycle closing ("periodicity"): on unless switched off.  Where it takes effect: the lane-pool pass of the two-launch
+ * schedule and the fused launch (PERIOD instantiations), the tile kernel when it runs samples to max_iter with 8x8
+ * sub-tiles -- a one-pass frame (PERIOD instantiation) and SSAA (always compiled in).  Where it does not: the effects
+ * variants, one-pass frames with 16x4 / 64x1 sub-tiles, the block-stage schedule ("staging" = 2), the fresh-pixel lane
+ * pool ("pool" = 2) and Deep_Zoom -- those iterate every sample to max_iter, as the reference does. */
+static uint32_t period_window(const fr_ctx* c)
+{
+    return c->tune_periodicity < 0 ? 0u : (c->tune_periodicity == 0 ? 128u : (uint32_t)c->tune_periodicity);
 }
 
 /* zero the queue heads and stream counters of the next render (a kernel, not a memset node: see clear_words_kernel) */
@@ -737,8 +748,9 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.q.run_shift = clamp_shift((int)ceil_log2(4u * waves_per_shard));
         a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
         if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
-        a.period_window = c->tune_periodicity;
+        a.period_window = period_window(c);
         a.diag = c->diag;
+        a.out.overflow = c->overflow_dev;                   /* no stream here: the word only carries the watchdog's report */
         hipError_t ef = by_variant(fractal, f64, [&](auto t, auto f) {
             return launch_fused<decltype(t), decltype(f)::value>(dim3(grid), stream, a); });
         if (ef != hipSuccess) return fr_set_error(FR_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString(ef));
@@ -772,8 +784,9 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
             constexpr int F = decltype(f)::value == 1 ? 0 : decltype(f)::value;      /* Julia has no effects variant */
             return launch_tile<decltype(t), F, true>(shape, dim3(grid), stream, a); });
     } else {
-        /* SSAA runs every sample to max_iter in the tile pass: cycle closing applies there (escape_run) */
-        a.period_window = !staged ? c->tune_periodicity : 0u;          /* a staged tile pass hands its survivors on */
+        /* a pass that runs its samples to max_iter closes cycles in escape_run: SSAA (any shape; always compiled in) and
+         * the one-sample kernel with 8x8 sub-tiles (its PERIOD instantiation, launch_tile) */
+        a.period_window = !staged ? period_window(c) : 0u;          /* a staged tile pass hands its survivors on */
         e = by_variant(fractal, f64, [&](auto t, auto f) {
             return launch_tile<decltype(t), decltype(f)::value, false>(shape, dim3(grid), stream, a); });
     }
@@ -811,7 +824,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
             a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
             if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
             a.out.base = nullptr;                                   /* the pool pass runs everything out */
-            a.period_window = c->tune_periodicity;
+            a.out.overflow = c->overflow_dev;                       /* ... and reports a stretch loop that will not end */
+            a.period_window = period_window(c);
             /* a lane-pool wave holds its claimed blocks as a private reserve and only stalls for a dequeue
              * once per reserve, so claim little and never ahead: what a wave has reserved when the queue
              * runs dry is exactly the tail of the pass (measured: 1-3 block runs + one run prefetched left

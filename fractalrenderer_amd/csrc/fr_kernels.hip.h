@@ -1433,18 +1433,34 @@ pool_kernel(const LaunchArgs A)
     uint32_t next_snap = 0;              /* wave-uniform: clock of the next snapshot */
     uint32_t snap_window = A.period_window, snap_closed = 1u;   /* current window; lanes closed since the last snapshot */
     const uint32_t snap_cap = A.period_window > (((uint32_t)A.max_iter >> 7) << 4) ? A.period_window : (((uint32_t)A.max_iter >> 7) << 4);
+    /* PERIOD, adaptive stride (see close_cycles): the wave's unchecked stretches are `stride` updates long once a cycle has
+     * told it what stride to compare at (0: blocks of 16); clock of the last snapshot; smallest offset a lane closed at
+     * since then */
+    uint32_t stride = 0, snap_time = 0, min_hit = 0xFFFFFFFFu;
+    bool learning = false;               /* a cycle was seen somewhere inside a stretch of several blocks: one block per
+                                          * stretch until the next one tells the offset exactly */
     /* wave-uniform state */
     uint32_t wclock = 0;
     uint32_t next_deadline = 0;          /* a lower bound of the earliest deadline among running lanes */
     bool have_running = false;
     uint32_t res_begin = 0, res_count = 0, res_shard = 0, res_next = 0;    /* reserve: run of 64-item groups, cursor in items */
+    uint32_t life_avg = 0;                    /* PERIOD: smoothed lifetime (updates since its refill) of retired lanes */
     bool dry = false, fast = false;
 
     FR_STAMP_DECL
     for (;;) {
         /* ---- retire: shade and store the finished lanes ---- */
         FR_STAMP_BEGIN();
-        if (__builtin_amdgcn_ballot_w64(fin != 0u) != 0ull) {
+        const uint64_t finm = __builtin_amdgcn_ballot_w64(fin != 0u);
+        if (finm != 0ull) {
+            if constexpr (PERIOD) {
+                /* lifetime of (the first of) the lanes retired now: its deadline was set to refill clock + remaining updates.
+                 * (Read with the lane's number, in uniform control flow: a readfirstlane inside the divergent block below
+                 * left the wave running on with the retiring lanes' EXEC mask -- the rest of the loop saw 17 lanes.) */
+                const uint32_t life = (uint32_t)__builtin_amdgcn_readlane((int)(wclock - (deadline - ((uint32_t)max_iter - (uint32_t)A.i0))),
+                                                                          (int)__builtin_ctzll(finm));
+                life_avg = life_avg == 0u ? life : (3u * life_avg + life) >> 2;
+            }
             if (fin != 0u) {
                 T nu;
                 float rgb[3];
@@ -1579,18 +1595,32 @@ pool_kernel(const LaunchArgs A)
         const uint32_t nactive = (uint32_t)__builtin_popcountll(active);
         /* a wave that can no longer refill is on the critical path of the launch: give it issue priority */
         if (dry) __builtin_amdgcn_s_setprio(3);
-        if constexpr (FROM_STREAM) {
-            /* records carry their own progress, so deadlines are not monotone: keep the true minimum */
+        if (FROM_STREAM && A.i0 == 0) {
+            /* records carry their own progress (block-stage schedules), so deadlines are not monotone: keep the true minimum */
             next_deadline = wclock + wave_min_u32<T>(pixel != kInvalidPixel ? deadline - wclock : 0xFFFFFFFFu);
             have_running = true;
         } else {
             /* refilled lanes get the LATEST deadline (wclock + max_iter), so the earliest one only
              * changes when it is reached: no reduction here */
-            if (!have_running) { next_deadline = wclock + (uint32_t)max_iter; have_running = true; }
+            if (!have_running) { next_deadline = wclock + (uint32_t)(max_iter - (FROM_STREAM ? A.i0 : 0)); have_running = true; }
         }
 
         /* ---- iterate until `goal` lanes have finished ---- */
-        const uint32_t goal = (dry || refill_at > nactive) ? nactive : refill_at;   /* queue dry: run the rest out */
+        /* How many idle lanes to wait for.  A retire + refill costs the wave about 40 updates' worth of instructions
+         * whatever the number of lanes it serves; waiting for k lanes that finish tau updates apart idles k^2 tau / 2
+         * lane-updates.  Per lane served that is 40 / k + k tau / 128, smallest at k = 72 / sqrt(tau): where lanes finish
+         * in quick succession (escape-dense records, or 64 interior lanes reaching one deadline) the configured
+         * threshold (24) is right, where they trickle out -- cycle closing on a deep view: one lane per ~150 updates --
+         * waiting for 24 keeps a fifth of the wave idle.  tau is taken from how long the lanes retired lately had lived
+         * (64 lanes of lifetime L finish L / 64 apart). */
+        uint32_t want = refill_at;
+        if constexpr (PERIOD) {
+            /* tau = (smoothed lifetime of the lanes retired lately) / 64 */
+            const uint32_t tau = life_avg >> 6;
+            want = tau >= 288u ? 4u : (tau >= 128u ? 6u : (tau >= 72u ? 8u : (tau >= 32u ? 12u : (tau >= 14u ? 18u : refill_at))));
+            if (want > refill_at) want = refill_at;
+        }
+        const uint32_t goal = (dry || want > nactive) ? nactive : want;             /* queue dry: run the rest out */
         uint32_t newly = 0;
         /* lanes whose deadline is reached are interior; then find the next earliest deadline */
         auto reach_deadline = [&](bool at_or_past) {
@@ -1600,7 +1630,8 @@ pool_kernel(const LaunchArgs A)
                 esc_i = max_iter; esc_r2 = T(0); fin = 1u;
                 o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
             }
-            newly += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+            const uint32_t nhit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+            newly += nhit;
             const uint32_t rel = wave_min_u32<T>((running && !hit) ? deadline - wclock : 0xFFFFFFFFu);
             have_running = rel != 0xFFFFFFFFu;
             next_deadline = wclock + (have_running ? rel : (uint32_t)max_iter);
@@ -1609,8 +1640,21 @@ pool_kernel(const LaunchArgs A)
          * cycle: the update is a deterministic function of (z, c), so it repeats for ever and the lane can never
          * escape.  It is interior with exactly the result the remaining iterations would give (index max_iter;
          * the plain colourings do not look at the final z).  Called where every running lane is known not to
-         * have escaped; also takes the next snapshot when its time has come. */
-        auto close_cycles = [&]() {
+         * have escaped; also takes the next snapshot when its time has come.
+         *
+         * WHERE to compare.  Comparing after every unchecked block sees a cycle of period p only at offsets (from the
+         * snapshot) that are multiples of lcm(16, p).  Short cycles (the period-1/2/3 components of shallow views) show
+         * within a block or three; the cycles of a deep view do not: in the C4 view the floating-point orbits settle on
+         * cycles of 78, 39, 156, ... updates (tools/cycle_study.py), lcm(16, 78) = 624, and with the window that needs
+         * plus the wait for the next snapshot a lane ran ~1 100 updates too long, every lane, every refill.  So the
+         * wave LEARNS its stride: `hit_off` is the offset at which a lane was first seen back at its snapshot (a
+         * multiple of its period, and in block mode of 16); from 256 up the wave switches to stretches of hit_off / 16
+         * updates with one comparison each -- every period whose 16-fold divides hit_off shows within hit_off, its
+         * first multiple of the stride typically a period or two away (78 at stride 39) -- and shrinks the window to
+         * twice the smallest offset anything closed at.  A window that closes nothing doubles (both modes); at the cap
+         * the stride is forgotten and learned again.  Any equality is a proof, whatever the stride: only WHEN a cycle
+         * is seen changes, never a pixel. */
+        auto close_cycles = [&](const uint32_t hit_off) {
             const bool running = pixel != kInvalidPixel && fin == 0u;
             const bool hit = running && cyc != 0u;
             if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
@@ -1621,39 +1665,103 @@ pool_kernel(const LaunchArgs A)
                 const uint32_t nhit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
                 newly += nhit;
                 snap_closed += nhit;
+                /* seen, but not at which block of the stretch: worth finding out only if the offset may be a long one
+                 * (a short period closes within a few blocks whatever the stride) */
+                if (hit_off == 0u) learning = stride == 0u && wclock - snap_time >= 256u + 4u * (uint32_t)kFastBlock;
+                else {
+                    learning = false;
+                    if (hit_off < min_hit) min_hit = hit_off;
+                    if (stride == 0u && hit_off >= 256u && hit_off <= (snap_cap >> 1) + 16u * (uint32_t)kFastBlock) {
+                        /* learn.  Offsets counted in whole blocks are multiples of 16 AND of the period: a sixteenth is a
+                         * stride whose multiples meet the period's within hit_off.  An offset that is not (tested
+                         * stretches since the snapshot) is still a multiple of the period: compare every hit_off. */
+                        stride = (hit_off & 15u) ? hit_off : hit_off >> 4;
+                        snap_window = hit_off;
+                        next_snap = wclock;                          /* re-align: stretches are counted from a fresh snapshot */
+                    }
+                }
             }
             if ((int32_t)(wclock - next_snap) >= 0) {
                 refX = o.X; refYd = o.Yd;          /* parked lanes hold 0 == 0: masked by `running` above */
-                /* a cycle of period p shows at offsets that are multiples of lcm(16, p): a window that closed
-                 * nothing is doubled (up to max_iter / 8), so deep views with long periods are reached without
-                 * making the short cycles of shallow views wait */
-                if (snap_closed == 0u && snap_window < snap_cap) snap_window <<= 1;
+                if (snap_closed == 0u) {
+                    /* a window that closed nothing is doubled (up to max_iter / 8); at the cap a learned stride is dropped */
+                    if (snap_window < snap_cap) snap_window <<= 1;
+                    else if (stride != 0u) { stride = 0u; snap_window = A.period_window; }
+                } else if (stride != 0u && min_hit != 0xFFFFFFFFu) {
+                    const uint32_t w2 = min_hit << 1;
+                    snap_window = w2 < stride ? stride : (w2 > snap_cap ? snap_cap : w2);
+                }
                 snap_closed = 0u;
+                min_hit = 0xFFFFFFFFu;
+                snap_time = wclock;
                 next_snap = wclock + snap_window;
             }
         };
         uint32_t clean = 0;            /* tested updates since the last escape */
         uint32_t streak = 0;           /* clean unchecked blocks in a row */
         uint32_t dirty_run = 0;        /* dirty unchecked stretches in a row */
+        /* Every wave must reach its exit whatever happens to the bookkeeping above: a running lane finishes within
+         * max_iter updates, so a stretch loop that has run max_iter + 4096 updates without reaching its goal is a bug.
+         * It then says so (the host fails the render: FR_ERR_INTERNAL) and retires what it holds as interior. */
+        const uint32_t watchdog = wclock + (uint32_t)max_iter + 4096u;
         while (newly < goal) {
+            if ((int32_t)(wclock - watchdog) > 0) {
+                if (lane == 0 && A.out.overflow) __hip_atomic_store(A.out.overflow, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef FR_WATCHDOG_DUMP
+                if (A.diag) {
+                    uint64_t first = 1;
+                    if (lane == 0) first = atomicAdd((unsigned long long*)&A.diag[15], 1ull);
+                    first = __builtin_amdgcn_readfirstlane((int)first);
+                    if (first == 0) {
+                        if (lane == 0) {
+                            A.diag[0] = wclock; A.diag[1] = next_deadline; A.diag[2] = have_running; A.diag[3] = goal; A.diag[4] = newly;
+                            A.diag[5] = nactive; A.diag[6] = stride; A.diag[7] = fast; A.diag[8] = watchdog; A.diag[9] = snap_window;
+                            A.diag[10] = next_snap; A.diag[11] = dry; A.diag[12] = life_avg; A.diag[13] = refill_at; A.diag[14] = (uint64_t)max_iter | ((uint64_t)A.i0 << 32);
+                        }
+                        A.diag[16 + lane] = ((uint64_t)pixel << 32) | (uint64_t)(uint32_t)(deadline - wclock);
+                        A.diag[80 + lane] = ((uint64_t)fin << 32) | (uint64_t)cyc;
+                    }
+                }
+#endif
+                if (pixel != kInvalidPixel && fin == 0u) {
+                    esc_i = max_iter; esc_r2 = T(0); fin = 1u;
+                    o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                }
+                break;
+            }
             if (fast) {
                 const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
                 /* after 2 (6) clean stretches in a row the wave runs 2 (4) blocks per snapshot / test (a half, a
                  * quarter of that overhead on the long interior runs that dominate deep views); a dirty one resets it */
-                const uint32_t reps = streak >= 6u ? 4u : (streak >= 2u ? 2u : 1u);
-                uint32_t seen = 0u;
-                for (uint32_t rep = 0; rep < reps; ++rep) {
+                uint32_t reps = streak >= 6u ? 4u : (streak >= 2u ? 2u : 1u);
+                if constexpr (PERIOD) { if (learning) reps = 1u; }
+                uint32_t len = reps * (uint32_t)kFastBlock;          /* updates of this stretch */
+                uint32_t seen = 0u;                                  /* PERIOD: lanes seen back at their snapshot */
+                bool strided = false, exact = reps == 1u;            /* exact: a lane seen back was seen at the stretch's end */
+                if constexpr (PERIOD) strided = stride != 0u;
+                if (strided) {
+                    /* learned stride: a whole number of strides, at least 64 updates, ONE comparison */
+                    len = stride * (stride >= 64u ? 1u : (63u + stride) / stride);
+                    exact = true;
+                    for (uint32_t b = len >> 4; b != 0u; --b) {
 #pragma unroll
-                    for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
-                    if constexpr (PERIOD) seen |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
+                        for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
+                    }
+                    for (uint32_t r = len & 15u; r != 0u; --r) orbit_step<T, Form<FRACTAL>::abs_step>(o);
+                    if constexpr (PERIOD) seen = (o.X == refX && o.Yd == refYd) ? 1u : 0u;
+                } else {
+                    for (uint32_t rep = 0; rep < reps; ++rep) {
+#pragma unroll
+                        for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
+                        if constexpr (PERIOD) seen |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
+                    }
                 }
                 const bool bad = !(orbit_r2x4(o) <= B2x4);
                 const uint64_t badm = __builtin_amdgcn_ballot_w64(bad);
                 if (badm != 0ull) {
                     /* dirty stretch: locate the escaped lanes' updates (locate_escapes), keep everybody else's progress */
                     uint32_t ek; T er;
-                    locate_escapes<T, Form<FRACTAL>::abs_step>(sX, sYd, sx2, sy2d, o.cx, o.cyd, B2x4, bad, badm,
-                                                               reps * (uint32_t)kFastBlock, ek, er);
+                    locate_escapes<T, Form<FRACTAL>::abs_step>(sX, sYd, sx2, sy2d, o.cx, o.cyd, B2x4, bad, badm, len, ek, er);
                     if (bad) {
                         /* an escape at or past the lane's deadline is no escape: the sample ran its max_iter updates */
                         const int idx = (int)(wclock + ek - (deadline - (uint32_t)max_iter));
@@ -1670,11 +1778,11 @@ pool_kernel(const LaunchArgs A)
                     ++streak;
                     dirty_run = 0;
                 }
-                wclock += reps * (uint32_t)kFastBlock;
+                wclock += len;
                 /* lanes at or past their deadline that are still running never escaped -> interior */
                 if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
                 /* (a lane that escaped inside the stretch is finished: close_cycles only looks at running lanes) */
-                if constexpr (PERIOD) { cyc |= seen; close_cycles(); }
+                if constexpr (PERIOD) { cyc |= seen; close_cycles(exact ? wclock - snap_time : 0u); }
                 continue;
             }
             /* tested stretch: up to the next deadline, at most one block.  The loop carries a countdown and
@@ -1709,12 +1817,20 @@ pool_kernel(const LaunchArgs A)
             if (wclock == next_deadline) reach_deadline(false);
             if constexpr (PERIOD) {
                 /* escaped lanes are parked and finished: only running lanes count, and those were tested every update */
-                cyc |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
-                close_cycles();
+                /* ... but not after a stretch in which something escaped: that is an escape-dense neighbourhood (a Julia
+                 * dust spends its whole pool pass in such stretches, and paid 8 % for looking); cycles are closed where
+                 * orbits run undisturbed */
+                if (!escaped) {
+                    cyc |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
+                    close_cycles(0u);
+                }
             }
             /* back to unchecked blocks after a block's worth of updates without an escape */
             if (clean >= (uint32_t)kFastBlock) { fast = fast_ok; clean = 0; }
         }
+#ifdef FR_STAMP
+        st_acc[1] = wclock;          /* pool: updates this wave has run (x 64 lanes = the lane-updates it paid for) */
+#endif
     }
     if (A.diag && lane == 0) {      /* as diag_write, with the dry time packed above the dequeue count */
         const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -1998,7 +2114,16 @@ fused_kernel(const LaunchArgs A)
             }
         };
         uint32_t clean = 0, streak = 0, dirty_run = 0;
+        const uint32_t watchdog = wclock + (uint32_t)max_iter + 4096u;       /* see pool_kernel */
         while (newly < goal) {
+            if ((int32_t)(wclock - watchdog) > 0) {
+                if (lane == 0 && A.out.overflow) __hip_atomic_store(A.out.overflow, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (pixel != kInvalidPixel && fin == 0u) {
+                    esc_i = max_iter; esc_r2 = T(0); fin = 1u;
+                    o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                }
+                break;
+            }
             if (fast) {
                 const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
                 const uint32_t reps = streak >= 6u ? 4u : (streak >= 2u ? 2u : 1u);

@@ -243,15 +243,18 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                        all 8 otherwise and on grids of fewer than 64 workgroups)
  *   "stream_rotate"      2 = survivor-stream writers rotate over the 8 regions (equal regions), 1 = one region
  *                        per XCD, 0 = automatic (= 2)
- *   "periodicity"        0 = off (default), 1 = on, N > 1 = on with a first snapshot window of N iterations.
- *                        The lane-pool pass (and the tile pass where it runs samples to max_iterations: SSAA, and
- *                        one-pass frames with 8x8 sub-tiles) keeps, per lane, the orbit state at the last snapshot; a lane whose
- *                        state returns to it is on a cycle, can never escape, and is retired as interior at once
- *                        instead of being iterated to max_iter.  Exact, not a heuristic: the update is a
- *                        deterministic function of (z, c), so every plane stays byte-identical
- *                        (tests/test_gpu_parity.py::test_periodicity_never_changes_a_pixel).  No reference
- *                        counterpart: the shaders iterate every interior sample to max_iter.  Off by default so
- *                        that the default path executes exactly the reference's iteration count.
+ *   "periodicity"        -1 = off, 0 = automatic (ON), 1 = on, N > 1 = on with a first snapshot window of N iterations.
+ *                        Cycle closing: the kernels keep, per lane, the orbit state at the wave's last snapshot; a lane whose
+ *                        state returns to it is on a cycle, can never escape, and is retired as interior at once instead
+ *                        of being iterated to max_iter.  Exact, not a heuristic: the update is a deterministic function
+ *                        of (z, c), so every plane stays byte-identical
+ *                        (tests/test_gpu_parity.py::test_periodicity_never_changes_a_pixel); what changes is the number of
+ *                        iterations executed -- the reference's shaders iterate every interior sample to max_iter (C2:
+ *                        1.4x fewer, a filled Julia set 2.8x; views without attracting cycles pay ~2 % for the compares).
+ *                        Takes effect in the lane-pool pass and the fused launch, and where the tile kernel itself runs
+ *                        samples to max_iter with 8x8 sub-tiles (one-pass frames, SSAA); not in the effects variants, the
+ *                        block-stage schedule, the fresh-pixel pool or Deep_Zoom.  bench.py's headline switches it OFF so
+ *                        that its roofline is quoted on the reference's iteration count.
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1
  *   "debug_region_blocks" tests only: caps the capacity of a survivor-stream region so that the overflow report
  *                        (FR_ERR_INTERNAL) can be exercised; 0 = the real capacity (1.5x the worst case)

@@ -220,8 +220,9 @@ def test_periodicity_never_changes_a_pixel(fr, renderer, oracle, name, window):
     """An orbit that returns to its own earlier state can never escape: the lane pool may call it interior
     at once.  Every plane must stay byte-identical to the run without the option, and match the oracle."""
     p, W, H = CASES[name]
-    base = gpu_render(fr, renderer, p, W, H)
     try:
+        renderer.set_option("periodicity", -1)       # off: what the reference executes
+        base = gpu_render(fr, renderer, p, W, H)
         renderer.set_option("periodicity", window)
         renderer.set_option("staging", 3)            # cycles are closed in the lane-pool pass: run it whatever max_iter is
         cur = gpu_render(fr, renderer, p, W, H)
@@ -252,9 +253,9 @@ def test_periodicity_on_interior_heavy_views(fr, renderer, oracle):
         for prec in (1, 0):
             p = oracle.OracleParams(precision=prec, **kw)
             W, H = 320, 200
-            base = gpu_render(fr, renderer, p, W, H)
-            t_off = renderer.last_kernel_ms()
             try:
+                renderer.set_option("periodicity", -1)
+                base = gpu_render(fr, renderer, p, W, H)
                 for opts in (dict(periodicity=1), dict(periodicity=32, pool_refill_at=1), dict(periodicity=256, pool_refill_at=64),
                              dict(periodicity=1, staging=1),                         # one pass: cycles closed in the tile kernel
                              dict(periodicity=16, staging=1, subtile_shape=4)):      # ... which only exists for 8x8 sub-tiles
@@ -280,9 +281,10 @@ def test_periodicity_on_interior_heavy_views(fr, renderer, oracle):
                dict(fractal=2, center_x=-0.5, center_y=-0.5, zoom=1.0, max_iterations=600, aa=2, precision=0),
                dict(fractal=1, center_x=0.0, zoom=2.0, julia_c_real=-0.12, julia_c_imag=0.74, max_iterations=900, aa=2)):
         p = oracle.OracleParams(**kw)
-        base = gpu_render(fr, renderer, p, 160, 96)
         try:
-            for window in (1, 16, 400):
+            renderer.set_option("periodicity", -1)
+            base = gpu_render(fr, renderer, p, 160, 96)
+            for window in (0, 1, 16, 400):
                 renderer.set_option("periodicity", window)
                 cur = gpu_render(fr, renderer, p, 160, 96)
                 for a, b in zip(base, cur):
@@ -292,13 +294,13 @@ def test_periodicity_on_interior_heavy_views(fr, renderer, oracle):
         ref = oracle.render(p, 160, 96)
         check_against(p, ref.iter, ref.nu, ref.rgba, *base)
     with pytest.raises(fr.FractalRendererError):
-        renderer.set_option("periodicity", -1)
+        renderer.set_option("periodicity", -2)
     # full size: the C2 frame, byte-identical and faster
     p, W, H = oracle.OracleParams(max_iterations=1024), 4096, 4096
     st = to_state(fr, p)
     planes = {}
     times = {}
-    for mode in (0, 1):
+    for mode in (-1, 0):                     # off / the default
         renderer.set_option("periodicity", mode)
         try:
             rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
@@ -313,9 +315,9 @@ def test_periodicity_on_interior_heavy_views(fr, renderer, oracle):
             renderer.set_option("periodicity", 0)
         planes[mode] = (rgba, nu, it)
         times[mode] = min(ts)
-    for a, b in zip(planes[0], planes[1]):
+    for a, b in zip(planes[-1], planes[0]):
         assert torch.equal(a, b)
-    assert times[1] < 0.85 * times[0], times
+    assert times[0] < 0.85 * times[-1], times
 
 
 def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
@@ -680,7 +682,7 @@ def test_c4_full_size(fr, renderer, oracle):
                        torch.empty((rows, W), dtype=torch.int32, device=dev))
     base = mk(H)
     try:
-        renderer.set_option("periodicity", 0)
+        renderer.set_option("periodicity", -1)                           # off: every interior sample runs its 16384 updates
         renderer.render(st, W, H, rgba=base[0], nu=base[1], iter=base[2])
         assert renderer.last_stages() == 2
         t_plain = renderer.last_kernel_ms()
@@ -690,7 +692,7 @@ def test_c4_full_size(fr, renderer, oracle):
         mean_it = float(torch.where(it < 16384, it.to(torch.int64) + 1, torch.full_like(it, 16384, dtype=torch.int64)).double().mean())
         assert abs(interior - 0.747) < 0.003 and abs(mean_it - 12555.0) < 30.0, (interior, mean_it)
         other = mk(H)
-        for opts in (dict(periodicity=1), dict(staging=1)):
+        for opts in (dict(periodicity=0), dict(periodicity=-1, staging=1)):
             for k, v in opts.items():
                 renderer.set_option(k, v)
             for t in other:
@@ -699,10 +701,9 @@ def test_c4_full_size(fr, renderer, oracle):
             renderer.render(st, W, H, rgba=other[0], nu=other[1], iter=other[2])
             for a, b in zip(base, other):
                 assert torch.equal(a, b), opts
-            if "periodicity" in opts:
+            if opts["periodicity"] == 0:
                 assert renderer.last_kernel_ms() < 0.85 * t_plain        # the interior runs are cut short
-            for k in opts:
-                renderer.set_option(k, 0)
+            renderer.set_option("staging", 0)
         del other
         renderer.set_option("periodicity", 1)                            # shards: with cycle closing (3x faster here)
         for layout_R in (H // 8, 32):                                    # 8 contiguous row bands; interleaved strips of 32

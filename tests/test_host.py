@@ -519,6 +519,10 @@ def test_hot_kernels_keep_their_register_budget(fr):
         "_ZN2fr11pool_kernelIdLi0ELi3ELb1ELb0EEEvNS_10LaunchArgsE": (80, 6, 16),   # fp64 Mandelbrot lane pool (C2/C4/C5)
         "_ZN2fr11pool_kernelIdLi0ELi3ELb1ELb1EEEvNS_10LaunchArgsE": (80, 6, 16),   # ... with cycle closing ("periodicity")
         "_ZN2fr11pool_kernelIfLi1ELi3ELb1ELb0EEEvNS_10LaunchArgsE": (64, 6, 8),    # fp32 Julia lane pool (C3)
+        "_ZN2fr11pool_kernelIfLi1ELi3ELb1ELb1EEEvNS_10LaunchArgsE": (64, 6, 8),    # ... with cycle closing (the default)
+        "_ZN2fr11tile_kernelIdLi0ELi3ELb0ELb0ELb1EEEvNS_10LaunchArgsE": (96, 5, 48),   # one-pass frames (C1), cycle closing
+        "_ZN2fr12fused_kernelIdLi0ELb0EEEvNS_10LaunchArgsE": (96, 5, 48),          # fused launch ("staging" = 4)
+        "_ZN2fr12fused_kernelIdLi0ELb1EEEvNS_10LaunchArgsE": (96, 5, 48),
         "_ZN2fr11tile_kernelIdLi0ELi3ELb0ELb0ELb0EEEvNS_10LaunchArgsE": (96, 5, 48),   # fp64 Mandelbrot tile pass
         "_ZN2fr11tile_kernelIfLi1ELi3ELb0ELb0ELb0EEEvNS_10LaunchArgsE": (64, 5, 24),   # fp32 Julia tile pass
         # the effects variant (orbit trap / stripes): its fp64 atan2 + sin epilogue holds it at 3 waves per SIMD

@@ -18,8 +18,11 @@ for name in names:
     ft, pr = fr.FractalType[w["fractal"]], fr.Precision[w["precision"]]
     nu_dt = torch.float64 if pr == fr.Precision.F64 else torch.float32
     planes = {}
-    for mode in [0] + windows:
-        r.set_option("periodicity", mode)
+    for mode in [-1] + windows:        # -1: off (the reference's iteration count)
+        try:
+            r.set_option("periodicity", mode)
+        except fr.FractalRendererError:      # a library from before the option's default became "on": 0 was "off"
+            r.set_option("periodicity", 0)
         rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
         nu = torch.empty((H, W), dtype=nu_dt, device="cuda:0")
         it = torch.empty((H, W), dtype=torch.int32, device="cuda:0")
@@ -29,11 +32,11 @@ for name in names:
             r.render(st, W, H, fractal_type=ft, precision=pr, rgba=rgba)
             ts.append(r.last_kernel_ms())
         same = ""
-        if mode == 0:
+        if mode == -1:
             planes = dict(rgba=rgba, nu=nu, it=it)
         else:
             same = "identical planes: %s" % all(torch.equal(a, b) for a, b in ((rgba, planes["rgba"]), (nu, planes["nu"]), (it, planes["it"])))
         print("%-3s periodicity %-4d  median %.4f ms  min %.4f ms  %8.0f Mpx/s  %s" % (
             name, mode, statistics.median(ts), min(ts), W * H / statistics.median(ts) / 1e3, same), flush=True)
         del rgba, nu, it
-r.set_option("periodicity", 0)
+r.set_option("periodicity", 0)   # back to the default (on)

@@ -36,6 +36,11 @@ for s in range(nst):
         continue
     life = (ds[ran, 1] - ds[ran, 0]) / 100.0
     print(f"  stage {s}: {ran.sum()} waves, mean wave lifetime {life.mean():.1f} us, items/wave {ds[ran,2].mean():.1f}, claims/wave {(ds[ran,3] & 0xFFFFFFFF).mean():.1f}")
+    if s >= 1:
+        wc = ds[ran, 5].astype(np.float64)
+        print(f"      wave clock (updates run per wave): mean {wc.mean():.0f}, total lane-update slots {wc.sum()*64:.4g}")
     for k in range(4):
+        if s >= 1 and k == 1:
+            continue
         us = ds[ran, 4 + k] / (GHZ * 1e3)
         print(f"      {names[k]:40s} mean {us.mean():8.2f} us/wave = {100*us.mean()/life.mean():5.1f} % of lifetime (p90 {np.percentile(us,90):.1f})")
