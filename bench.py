@@ -75,6 +75,32 @@ WORKLOADS = {
                 fractal="Mandelbrot", precision="F32", W=3840, H=2160, cpu_rows=2160, state=dict(max_iterations=256)),
     "uhd1k": dict(desc="interactive size: mandelbrot 3840x2160 max_iter=1024 fp64 default viewport",
                   fractal="Mandelbrot", precision="F64", W=3840, H=2160, cpu_rows=2160, state=dict(max_iterations=1024)),
+    # the other kernels of the path (each with its own bound; profiles/r02_*): the reference's perturbation shader, the
+    # effects variant of the tile kernel, and -- `kernel` entries, no render in the timed region -- the recolour and the
+    # two export kernels of the frame-output path
+    "deepzoom": dict(desc="Deep_Zoom (shaders/test_deep_zoom.comp: fp32 perturbation against an fp64 reference orbit) 4096x4096 "
+                          "max_iter=2000 seahorse zoom 1e-6",
+                     fractal="Deep_Zoom", precision="F32", W=4096, H=4096, cpu_rows=256, flops_per_update=23,
+                     state=dict(max_iterations=2000, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-6,
+                                use_perturbation=True)),
+    "trap": dict(desc="effects variant: mandelbrot 4096x4096 max_iter=1024 fp64 default viewport, orbit trap blend "
+                      "(shaders/mandelbrot.comp:163-166,193-198)",
+                 fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=512,
+                 state=dict(max_iterations=1024, orbit_trap_enabled=True)),
+    "stripes": dict(desc="effects variant: mandelbrot 4096x4096 max_iter=1024 fp64 default viewport, stripe shading "
+                         "(shaders/mandelbrot.comp:201-205)",
+                    fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=512,
+                    state=dict(max_iterations=1024, stripe_enabled=True)),
+    "colorize": dict(desc="fr_colorize_async: colour from the fp64 smooth-count plane of the C2 frame, 4096x4096 "
+                          "(8 B read + 16 B written per pixel)", kernel="colorize", bytes_per_pixel=24,
+                     fractal="Mandelbrot", precision="F64", W=4096, H=4096, state=dict(max_iterations=1024)),
+    "export8": dict(desc="fr_export_rgb8: RGBA f32 -> RGB8 (fp16 rounding, ACES, gamma, truncation, flip; "
+                         "src/vk_engine.cpp:1344-1371), 4096x4096 (16 B read + 3 B written per pixel)",
+                    kernel="export8", bytes_per_pixel=19,
+                    fractal="Mandelbrot", precision="F64", W=4096, H=4096, state=dict(max_iterations=1024)),
+    "export16": dict(desc="fr_export_rgb16: RGBA f32 -> RGB16 (clamp, truncation, flip; src/vk_engine.cpp:2054-2073), 8192x8192 "
+                          "(16 B read + 6 B written per pixel)", kernel="export16", bytes_per_pixel=22,
+                     fractal="Mandelbrot", precision="F64", W=8192, H=8192, state=dict(max_iterations=256)),
     # diagnostic only (tools/timeline.py, tools/sweep_opts.py): every pixel escapes at i <= 1 -- the per-pixel skeleton
     "far": dict(desc="diagnostic: far-exterior view, mandelbrot 4096x4096 max_iter=1024 fp64 centre (8,8) zoom 2",
                 fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=4096,
@@ -93,8 +119,9 @@ def cpu_baseline(workload: dict) -> dict:
     O.build()
     w = workload
     st = w["state"]
-    p = O.OracleParams(fractal=0 if w["fractal"] == "Mandelbrot" else 1, precision=1 if w["precision"] == "F64" else 0,
-                       **{("max_iterations" if k == "max_iterations" else k): v for k, v in st.items()})
+    fmap = {"Mandelbrot": 0, "JuliaSet": 1, "BurningShip": 2, "Deep_Zoom": 5}
+    p = O.OracleParams(fractal=fmap[w["fractal"]], precision=1 if w["precision"] == "F64" else 0,
+                       **{k: (int(v) if isinstance(v, bool) else v) for k, v in st.items()})
     W, H = w["W"], w["H"]
     bands = 16
     band_rows = max(1, w.get("cpu_rows", 1024) // bands)      # sized for ~10-30 core-seconds of CPU work
@@ -301,6 +328,77 @@ def cpu_rehearsal(args) -> None:
         raise SystemExit(4)
 
 
+def kernel_workload(args, w) -> None:
+    """--workload colorize | export8 | export16: one step = ONE launch of that kernel over a resident plane (the render
+    that produces its input is outside the timed region).  HBM-bound kernels: roofline = algorithmic bytes / HIP-event time."""
+    import numpy as np
+    import torch
+    import fractalrenderer_amd as fr
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    dev = torch.device("cuda", 0)
+    W, H = w["W"], w["H"]
+    r = fr.Renderer(0)
+    state = fr.FractalState(**w["state"])
+    kind = w["kernel"]
+    rgba = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    nu = torch.empty((H, W), dtype=torch.float64, device=dev)
+    r.render(state, W, H, rgba=rgba, nu=nu, post_chain=(kind != "colorize"))
+    stream = torch.cuda.Stream(device=dev)
+    h = stream.cuda_stream
+    if kind == "colorize":
+        out = torch.empty_like(rgba)
+        step = lambda: r.colorize(state, nu, out, stream=h)                                   # noqa: E731
+    elif kind == "export8":
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        step = lambda: r.export_rgb8(rgba, W, H, out=out, through_half=True, stream=h)        # noqa: E731
+    else:
+        out = torch.empty((H, W, 3), dtype=torch.int16, device=dev)
+        step = lambda: r.export_rgb16(rgba, W, H, out=out, stream=h)                          # noqa: E731
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    if kind == "colorize":                      # the recoloured plane IS the rendered one
+        verified = bool(torch.equal(out, rgba))
+    else:                                       # against the synchronous entry point
+        ref = r.export_rgb8(rgba, W, H, through_half=True) if kind == "export8" else r.export_rgb16(rgba, W, H)
+        verified = bool(torch.equal(out, ref))
+    bpp = w["bytes_per_pixel"]
+    gbs = bpp * W * H / (kernel_ms * 1e-3) / 1e9
+    line = {"metric": f"Mpixels/s ({args.workload})", "value": round(args.steps * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["desc"], "compute_units": r.compute_units},
+            "output_verified": verified,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                         "traffic": pmc_traffic(args.workload), "kernel_ms": round(kernel_ms, 4),
+                         "note": f"algorithmic bytes {bpp} B/pixel; the guide's measured streaming ceiling is ~6.3 TB/s (79 % of spec)"}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        O.build()
+        rows = 512
+        src = rgba[:rows].cpu().numpy()
+        t1 = time.perf_counter()
+        if kind == "colorize":
+            O.colorize(O.OracleParams(max_iterations=state.max_iterations), nu[:rows].cpu().numpy())
+        else:
+            O.export_rgb8(src, through_half=True)     # the restated CPU loop of src/vk_engine.cpp:1344-1371 (8-bit form for both)
+        dtc = time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": round(rows * W / dtc / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                                "sample": f"{rows} rows of the same plane, oracle (single thread), {dtc:.2f} s"}
+    print(json.dumps(line), flush=True)
+    r.close()
+
+
 def main() -> None:
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -312,6 +410,12 @@ def main() -> None:
         if args.gpus < 2:
             raise SystemExit("--cpu-rehearsal rehearses the N > 1 path: use --gpus 2 or more")
         cpu_rehearsal(args)
+        return
+
+    if "kernel" in WORKLOADS[args.workload]:
+        if args.gpus != 1:
+            raise SystemExit("kernel workloads are single-GPU")
+        kernel_workload(args, WORKLOADS[args.workload])
         return
 
     import numpy as np
@@ -580,14 +684,18 @@ def main() -> None:
                                "kernel_ms": round(kernel_ms, 4), "kernel_ms_last_launch": round(last_ms, 4),
                                "note": "the metric's HBM roofline; the kernel is fp64-VALU-bound, see roofline_valu"}
             peak = FP64_VALU_PEAK_TOPS if prec == fr.Precision.F64 else FP32_VALU_PEAK_TOPS
-            tops = 8.0 * executed / (kernel_ms * 1e-3) / 1e12
+            fpu = float(w.get("flops_per_update", 8))
+            tops = fpu * executed / (kernel_ms * 1e-3) / 1e12
             out["roofline_valu"] = {"bound": "valu_" + out["dtype"], "achieved": round(tops, 3), "peak": peak,
-                                    "unit": "Tflop/s (8 flop per executed iteration, no FMA credit)",
+                                    "unit": f"Tflop/s ({fpu:g} flop per executed iteration, no FMA credit)",
                                     "frac": round(tops / peak, 4),
-                                    "issue_frac": round(tops * 6.0 / 8.0 / peak, 4),
+                                    "issue_frac": round(tops * 6.0 / 8.0 / peak, 4) if fpu == 8 else None,
                                     "issue_note": "the kernels issue 6 VALU instructions per update (two are FMAs by exact powers of "
                                                   "two standing for two as-written operations each): frac prices the 8 as-written "
-                                                  "flops and can exceed 1, issue_frac prices the 6 instructions",
+                                                  "flops and can exceed 1, issue_frac prices the 6 instructions" if fpu == 8 else
+                                                  "as-written operations of one perturbed update, shaders/test_deep_zoom.comp:153-173: "
+                                                  "2 complex products with the reference point and delta (6 + 5), three additions of "
+                                                  "pairs (6), z = ref + delta (2), dot(z, z) (3), compare (1)",
                                     "valu_busy_pmc": pmc_valu_busy(args.workload),
                                     "executed_iterations": executed,
                                     "mean_iterations_per_pixel": round(executed / (W * H), 2)}

@@ -1004,9 +1004,9 @@ extern "C" int fr_colorize_async(fr_ctx* c, const fr_params* p, uint64_t n_pixel
 
 static size_t export_blocks(const fr_ctx* c, size_t npx)
 {
-    size_t blocks = (npx + kBlockThreads - 1) / kBlockThreads;
+    size_t blocks = ((npx + 3) / 4 + kBlockThreads - 1) / kBlockThreads;     /* four pixels per thread */
     const size_t cap = (size_t)c->compute_units * 8;
-    return blocks > cap ? cap : blocks;
+    return blocks > cap ? cap : (blocks < 1 ? 1 : blocks);
 }
 
 static hipError_t launch_export(const fr_ctx* c, const float4* in, uint8_t* out, uint32_t W, uint32_t H, int through_half,

@@ -2367,47 +2367,90 @@ deep_zoom_kernel(const DeepZoomArgs A)
     }
 }
 
-/* ---- 8-bit export: src/vk_engine.cpp:1344-1371 on the GPU ------------------------------------ */
+/* ---- exports: RGBA f32 -> packed RGB8 / RGB16, flipped (src/vk_engine.cpp:1344-1371, :2054-2073) ---------------------
+ * HBM-bound by design: 16 B read + 3 (6) B written per pixel.  A thread converts FOUR consecutive pixels of an output
+ * row -- four 16-byte loads in flight, 12 (24) output bytes stored as three dwords (dwordx2s): whole 128-byte lines per
+ * wave-instruction instead of single bytes at a stride of three -- and the gamma of the 8-bit path is the hardware
+ * exp2(log2 x / 2.2) (what a GLSL pow lowers to; the reference's is MSVC's powf): it differs from a correctly rounded
+ * powf in the last ulp or two, i.e. in the 8-bit result only for a value within 1e-6 of a truncation edge.  Frames whose
+ * width is not a multiple of four take the one-pixel-per-thread form. */
+__device__ __forceinline__ float half_round(float f) { return __half2float(__float2half_rn(f)); }
+
+__device__ __forceinline__ uint32_t to_u8(float f, const int through_half)
+{
+    if (through_half) f = half_round(f);
+    f = aces(f);                                                              /* :1366 */
+    f = pow01(f, 1.0f / 2.2f);                                                /* :1367; aces() clamps to [0, 1] */
+    return (uint32_t)(f * 255.0f);                                            /* :1368 (truncation) */
+}
+__device__ __forceinline__ uint32_t to_u16(float f, const int through_half)
+{
+    if (through_half) f = half_round(f);
+    f = f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f);                              /* :2068 */
+    return (uint32_t)(f * 65535.0f);                                          /* :2069 */
+}
+
 __global__ void __launch_bounds__(kBlockThreads)
-export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8,
-                   int W, int H, int through_half)
+export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8, int W, int H, int through_half)
 {
     const size_t n = (size_t)W * (size_t)H;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(idx / (size_t)W), x = (int)(idx - (size_t)y * W);
-        const int flipped = H - 1 - y;                                        /* :1359 */
-        const float4 v = rgba[(size_t)flipped * W + x];
-        float c[3] = {v.x, v.y, v.z};
-        uint8_t q[3];
-        for (int k = 0; k < 3; ++k) {
-            float f = c[k];
-            if (through_half) f = __half2float(__float2half_rn(f));
-            f = aces(f);                                                      /* :1366 */
-            f = powf(f, 1.0f / 2.2f);                                         /* :1367 */
-            q[k] = (uint8_t)(f * 255.0f);                                     /* :1368 */
+    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((W & 3) == 0) {
+        const size_t quads = n >> 2, wq = (size_t)W >> 2;
+        uint32_t* out = reinterpret_cast<uint32_t*>(rgb8);                    /* 12 bytes per quad: 4-byte aligned */
+        for (size_t q = first; q < quads; q += stride) {
+            const size_t y = q / wq, x = (q - y * wq) << 2;
+            const float4* src = rgba + (size_t)(H - 1 - (int)y) * W + x;       /* :1359 flip */
+            const float4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+            const uint32_t b[12] = {to_u8(p0.x, through_half), to_u8(p0.y, through_half), to_u8(p0.z, through_half),
+                                    to_u8(p1.x, through_half), to_u8(p1.y, through_half), to_u8(p1.z, through_half),
+                                    to_u8(p2.x, through_half), to_u8(p2.y, through_half), to_u8(p2.z, through_half),
+                                    to_u8(p3.x, through_half), to_u8(p3.y, through_half), to_u8(p3.z, through_half)};
+            uint32_t* o = out + q * 3;
+            o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+            o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
         }
-        rgb8[idx * 3 + 0] = q[0]; rgb8[idx * 3 + 1] = q[1]; rgb8[idx * 3 + 2] = q[2];
+        return;
+    }
+    for (size_t idx = first; idx < n; idx += stride) {
+        const int y = (int)(idx / (size_t)W), x = (int)(idx - (size_t)y * W);
+        const float4 v = rgba[(size_t)(H - 1 - y) * W + x];
+        rgb8[idx * 3 + 0] = (uint8_t)to_u8(v.x, through_half);
+        rgb8[idx * 3 + 1] = (uint8_t)to_u8(v.y, through_half);
+        rgb8[idx * 3 + 2] = (uint8_t)to_u8(v.z, through_half);
     }
 }
 
-/* ---- 16-bit export: src/vk_engine.cpp:2054-2073 on the GPU (no second tonemap, clamp, truncate) ---- */
 __global__ void __launch_bounds__(kBlockThreads)
-export_rgb16_kernel(const float4* __restrict__ rgba, uint16_t* __restrict__ rgb16,
-                    int W, int H, int through_half)
+export_rgb16_kernel(const float4* __restrict__ rgba, uint16_t* __restrict__ rgb16, int W, int H, int through_half)
 {
     const size_t n = (size_t)W * (size_t)H;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(idx / (size_t)W), x = (int)(idx - (size_t)y * W);
-        const float4 v = rgba[(size_t)(H - 1 - y) * W + x];                       /* :2058 flip */
-        const float c[3] = {v.x, v.y, v.z};
-        for (int k = 0; k < 3; ++k) {
-            float f = c[k];
-            if (through_half) f = __half2float(__float2half_rn(f));
-            f = f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f);                          /* :2068 */
-            rgb16[idx * 3 + k] = (uint16_t)(f * 65535.0f);                        /* :2069 */
+    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((W & 3) == 0) {
+        const size_t quads = n >> 2, wq = (size_t)W >> 2;
+        uint2* out = reinterpret_cast<uint2*>(rgb16);                         /* 24 bytes per quad: 8-byte aligned */
+        for (size_t q = first; q < quads; q += stride) {
+            const size_t y = q / wq, x = (q - y * wq) << 2;
+            const float4* src = rgba + (size_t)(H - 1 - (int)y) * W + x;       /* :2058 flip */
+            const float4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+            const uint32_t h[12] = {to_u16(p0.x, through_half), to_u16(p0.y, through_half), to_u16(p0.z, through_half),
+                                    to_u16(p1.x, through_half), to_u16(p1.y, through_half), to_u16(p1.z, through_half),
+                                    to_u16(p2.x, through_half), to_u16(p2.y, through_half), to_u16(p2.z, through_half),
+                                    to_u16(p3.x, through_half), to_u16(p3.y, through_half), to_u16(p3.z, through_half)};
+            uint2* o = out + q * 3;
+            o[0] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            o[1] = make_uint2(h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            o[2] = make_uint2(h[8] | (h[9] << 16), h[10] | (h[11] << 16));
         }
+        return;
+    }
+    for (size_t idx = first; idx < n; idx += stride) {
+        const int y = (int)(idx / (size_t)W), x = (int)(idx - (size_t)y * W);
+        const float4 v = rgba[(size_t)(H - 1 - y) * W + x];
+        rgb16[idx * 3 + 0] = (uint16_t)to_u16(v.x, through_half);
+        rgb16[idx * 3 + 1] = (uint16_t)to_u16(v.y, through_half);
+        rgb16[idx * 3 + 2] = (uint16_t)to_u16(v.z, through_half);
     }
 }
 

@@ -21,10 +21,10 @@ for d in ("pmc_write", "pmc_fetch", "pmc_sq_a", "pmc_sq_b"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in [newest(f"{src}/{d}/**/*_counter_collection.csv")]:
         for r in csv.DictReader(open(f)):
-            m = re.search(r"fr::(\w+)<([^>]*)>", r["Kernel_Name"])
-            if not m:
+            m = re.search(r"fr::(\w+)(?:<([^>]*)>)?", r["Kernel_Name"])
+            if not m or m.group(1) == "clear_words_kernel":
                 continue
-            kn = f"{m.group(1)}<{m.group(2)}>"
+            kn = f"{m.group(1)}<{m.group(2)}>" if m.group(2) is not None else m.group(1)
             acc[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
             pmc[kn]["_launch"] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count")}
     for kn, cs in acc.items():
@@ -37,7 +37,14 @@ line = [l for l in open(os.path.join(src, "stats.log")) if l.startswith('{"metri
 if line:
     out["bench_line_under_kernel_trace"] = json.loads(line[0])
 ks = list(csv.DictReader(open(stats)))
-out["kernel_trace_avg_ns"] = {r["Name"][:80]: float(r["AverageNs"]) for r in ks if "fr::" in r["Name"]}
+out["kernel_trace_avg_ns"] = {r["Name"][:80]: float(r["AverageNs"]) for r in ks if "fr::" in r["Name"] and "clear_words" not in r["Name"]}
+# kernel workloads (colorize / export): the render that produces their input runs once, outside the timed region -- only the
+# kernel under test counts as "the frame"
+if workload in ("colorize", "export8", "export16"):
+    key = {"colorize": "colorize_kernel", "export8": "export_rgb8_kernel", "export16": "export_rgb16_kernel"}[workload]
+    out["kernel_trace_avg_ns"] = {k: v for k, v in out["kernel_trace_avg_ns"].items() if key in k}
+    frame = collections.defaultdict(float, {k: v["mean"] for kn, cs in pmc.items() if key in kn for k, v in cs.items() if isinstance(v, dict) and "mean" in v})
+    out["per_frame_sum_over_kernels"] = dict(frame)
 out["kernel_trace_frame_ms"] = sum(out["kernel_trace_avg_ns"].values()) / 1e6
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 # HBM traffic per frame, as MI355X_MICROARCH.md prescribes: WRITE_SIZE is exact for 16 B/lane streaming
