@@ -526,6 +526,18 @@ struct WaveQueue {
     /* hands out the next run [begin, begin+count) of shard `sh`; false = no work left anywhere */
     __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& count, uint32_t& sh)
     {
+        const bool got = next_(begin, count, sh);
+        /* Every claim above has been waited for and read -- but not as far as the compiler's s_waitcnt pass can tell on
+         * every path: it carried "a returning atomic may still be writing this VGPR" into the callers' loops and put an
+         * s_waitcnt vmcnt(0) in front of the first instruction that reuses the register -- EVERY sub-tile of the tile pass
+         * then waited for the previous sub-tile's stores to be acknowledged (found in the ISA; SQ_WAIT_ANY was 47 % of
+         * the tile pass's wave-cycles).  One wait the pass can see, here, where nothing is in flight anyway, clears
+         * its scoreboard.  (vmcnt(0), expcnt / lgkmcnt untouched: simm16 0x0F70 on gfx9.) */
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        return got;
+    }
+    __device__ __forceinline__ bool next_(uint32_t& begin, uint32_t& count, uint32_t& sh)
+    {
         /* shards known to be empty cost no atomic (a follow-up pass may have nothing to do) */
         while (shard_len(shard) == 0u) {
             if (++tried >= max_tries) return false;
