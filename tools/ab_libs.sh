@@ -6,7 +6,7 @@ for w in "$@"; do
   for i in $(seq 1 "$R"); do
     for L in "$A" "$B"; do
       printf "%s %s " "$w" "$(basename "$L")"
-      FR_LIB_PATH="$L" python tools/sweep_opts.py "$w" 15 "" 2>/dev/null | tail -1
+      FR_LIB_PATH="$L" python tools/sweep_opts.py "$w" 15 "${AB_OPTS:-}" 2>/dev/null | tail -1
     done
   done
 done
