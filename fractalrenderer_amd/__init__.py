@@ -9,7 +9,7 @@ from ._capi import FractalRendererError, lib
 from .state import (FractalState, FractalType, Precision, Preset, MANDELBROT_PRESETS,
                     SEAHORSE_DEEP, pack_push_constants)
 from .renderer import Renderer, Shard, write_png, write_raw_rgb24, frame_path
-from .animation import (AnimationSystem, AnimationRenderer, InterpolationType, Keyframe)
+from .animation import (AnimationSystem, AnimationRenderer, InterpolationType, Keyframe, DeepZoomPath, ZoomKeyframe)
 
 lib()  # no silent fallback: a missing/incomplete library is an import error
 
@@ -17,5 +17,5 @@ __all__ = [
     "FractalRendererError", "lib", "FractalState", "FractalType", "Precision", "Preset",
     "MANDELBROT_PRESETS", "SEAHORSE_DEEP", "pack_push_constants", "Renderer", "Shard",
     "write_png", "write_raw_rgb24", "frame_path",
-    "AnimationSystem", "AnimationRenderer", "InterpolationType", "Keyframe",
+    "AnimationSystem", "AnimationRenderer", "InterpolationType", "Keyframe", "DeepZoomPath", "ZoomKeyframe",
 ]

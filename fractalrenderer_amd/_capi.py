@@ -59,6 +59,10 @@ class fr_png_text(C.Structure):
     _fields_ = [("key", C.c_char_p), ("text", C.c_char_p)]
 
 
+class fr_zoom_keyframe(C.Structure):
+    _fields_ = [("center_x", C.c_double), ("center_y", C.c_double), ("zoom", C.c_double), ("duration", C.c_float)]
+
+
 class fr_anim_info(C.Structure):
     _fields_ = [("duration", C.c_float), ("loop", C.c_int32), ("target_fps", C.c_int32),
                 ("export_width", C.c_int32), ("export_height", C.c_int32), ("keyframe_count", C.c_int32)]
@@ -112,6 +116,12 @@ SIGNATURES = {
     "fr_anim_state_at": (C.c_int, [C.c_void_p, C.c_float, _P(fr_params), _P(fr_params)]),
     "fr_anim_frame_count": (C.c_int32, [C.c_void_p]),
     "fr_anim_frame_time": (C.c_float, [C.c_void_p, C.c_int32]),
+    "fr_zoom_path_create": (C.c_int, [_P(C.c_void_p)]),
+    "fr_zoom_path_free": (None, [C.c_void_p]),
+    "fr_zoom_path_play": (C.c_int, [C.c_void_p, _P(fr_zoom_keyframe), C.c_int32]),
+    "fr_zoom_path_zoom_to": (C.c_int, [C.c_void_p, _P(fr_params), C.c_double, C.c_double, C.c_double, C.c_float]),
+    "fr_zoom_path_update": (C.c_int, [C.c_void_p, C.c_float, _P(fr_params), _P(C.c_int32), _P(C.c_float), _P(C.c_int32)]),
+    "fr_zoom_preset": (C.c_int, [C.c_int32, _P(fr_zoom_keyframe)]),
     "fr_reference_orbit": (C.c_int, [C.c_double, C.c_double, C.c_int32, C.c_void_p, _P(C.c_int32)]),
     "fr_last_error": (C.c_char_p, []),
     "fr_status_string": (C.c_char_p, [C.c_int]),

@@ -162,3 +162,65 @@ class AnimationRenderer:
             if self.on_frame_complete:
                 self.on_frame_complete(frame, self.total_frames)   # :124-126
         return True
+
+
+@dataclass
+class ZoomKeyframe:
+    """src/deep_zoom_system.h:84-89 (centre / zoom are the reference's double-backed ArbitraryFloat)"""
+    center_x: float = 0.0
+    center_y: float = 0.0
+    zoom: float = 1.0
+    duration: float = 0.0
+
+
+class DeepZoomPath:
+    """The zoom-path animation of DeepZoomManager (src/deep_zoom_system.cpp:454-556): playZoomPath, zoomTo,
+    update_animation.  `state` is the FractalState it moves (the reference's DeepZoomState centre / zoom).
+    All arithmetic is in the C library (fractalrenderer_amd/csrc/fr_zoompath.c)."""
+
+    PRESETS = ("Seahorse", "Elephant", "MiniMandelbrot")        # DeepZoomPresets, :575-601
+
+    def __init__(self, state: Optional[FractalState] = None):
+        self._lib = _capi.lib()
+        self.state = state if state is not None else FractalState()
+        self.zoom_animating = False
+        self.zoom_progress = 0.0
+        h = C.c_void_p()
+        _capi.check(self._lib.fr_zoom_path_create(C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.fr_zoom_path_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def preset(which) -> ZoomKeyframe:
+        idx = DeepZoomPath.PRESETS.index(which) if isinstance(which, str) else int(which)
+        k = _capi.fr_zoom_keyframe()
+        _capi.check(_capi.lib().fr_zoom_preset(idx, C.byref(k)))
+        return ZoomKeyframe(k.center_x, k.center_y, k.zoom, k.duration)
+
+    def play_zoom_path(self, path: List[ZoomKeyframe]) -> None:
+        arr = (_capi.fr_zoom_keyframe * max(1, len(path)))()
+        for i, k in enumerate(path):
+            arr[i].center_x, arr[i].center_y, arr[i].zoom, arr[i].duration = k.center_x, k.center_y, k.zoom, k.duration
+        _capi.check(self._lib.fr_zoom_path_play(self._h, arr, len(path)))
+        self.zoom_animating, self.zoom_progress = bool(path), 0.0
+
+    def zoom_to(self, target_x: float, target_y: float, target_zoom: float, duration: float) -> None:
+        p = self.state.to_params()
+        _capi.check(self._lib.fr_zoom_path_zoom_to(self._h, C.byref(p), target_x, target_y, target_zoom, duration))
+        self.zoom_animating, self.zoom_progress = True, 0.0
+
+    def update_animation(self, delta_time: float) -> bool:
+        """Advances the path; returns True where the reference recomputes its reference orbit (a keyframe was reached)."""
+        p = self.state.to_params()
+        anim, dirty, prog = C.c_int32(), C.c_int32(), C.c_float()
+        _capi.check(self._lib.fr_zoom_path_update(self._h, delta_time, C.byref(p), C.byref(anim), C.byref(prog), C.byref(dirty)))
+        self.state.center_x, self.state.center_y, self.state.zoom = p.center_x, p.center_y, p.zoom
+        self.zoom_animating, self.zoom_progress = bool(anim.value), float(prog.value)
+        return bool(dirty.value)

@@ -411,6 +411,32 @@ float   fr_anim_frame_time(const fr_anim* a, int32_t frame);
  * pairs; *out_len receives the trimmed length. */
 int fr_reference_orbit(double cx, double cy, int32_t max_iter, double* out_xy, int32_t* out_len);
 
+/* ---- deep-zoom zoom paths ---------------------------------------------------------------------
+ * DeepZoomManager's zoom-path animation, src/deep_zoom_system.cpp:454-556 (host side in the reference too): a list of
+ * ZoomKeyframes (src/deep_zoom_system.h:84-89; centre and zoom are "ArbitraryFloat"s that hold a double) walked by
+ * update_animation(delta_time): centre linear, zoom in log space, the view snapped onto a keyframe when its duration
+ * has passed.  *orbit_dirty is set where the reference recomputes its reference orbit (:505); here the next
+ * fr_render of a Deep_Zoom frame does that anyway. */
+typedef struct fr_zoom_keyframe {
+    double center_x, center_y, zoom;
+    float  duration;               /* seconds from the previous keyframe to this one */
+} fr_zoom_keyframe;
+typedef struct fr_zoom_path fr_zoom_path;
+
+int  fr_zoom_path_create(fr_zoom_path** out);
+void fr_zoom_path_free(fr_zoom_path* z);
+/* playZoomPath, :454-460 (n == 0: nothing to play) */
+int  fr_zoom_path_play(fr_zoom_path* z, const fr_zoom_keyframe* path, int32_t n);
+/* zoomTo, :462-485: from `current`'s view (a start keyframe of duration 0) to the target in `duration` seconds */
+int  fr_zoom_path_zoom_to(fr_zoom_path* z, const fr_params* current, double target_x, double target_y, double target_zoom,
+                          float duration);
+/* update_animation, :487-531: advances by delta_time and writes centre / zoom into *state; *animating and *progress
+ * mirror DeepZoomState::zoom_animating / zoom_progress (src/deep_zoom_system.h:115-116).  Output pointers may be NULL. */
+int  fr_zoom_path_update(fr_zoom_path* z, float delta_time, fr_params* state, int32_t* animating, float* progress,
+                         int32_t* orbit_dirty);
+/* DeepZoomPresets, :575-601: 0 Seahorse (1e-6, 5 s), 1 Elephant (1e-8, 7 s), 2 Mini Mandelbrot (1e-10, 10 s) */
+int  fr_zoom_preset(int32_t which, fr_zoom_keyframe* out);
+
 /* ---- misc ---------------------------------------------------------------------------------- */
 
 const char* fr_last_error(void);

@@ -41,6 +41,28 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < sizeof img; ++i) img[i] = (unsigned char)(i * 2654435761u >> 13);
     if (fr_write_png(p1, 4001, 300, 8, img, NULL, 0, 0) != FR_OK) return 3;
     if (fr_write_png(p2, 2000, 300, 16, img, NULL, 0, 1) != FR_OK) return 4;
+    {   /* zoom paths: random keyframe lists walked with random time steps, replayed, emptied */
+        fr_zoom_path* z = NULL; if (fr_zoom_path_create(&z) != FR_OK) return 7;
+        fr_params st; fr_params_default(&st);
+        for (int t = 0; t < 200; ++t) {
+            fr_zoom_keyframe kf[6]; int nk = (int)((s = s * 1103515245u + 12345u) >> 28) % 7;
+            for (int k = 0; k < nk && k < 6; ++k) {
+                s = s * 1103515245u + 12345u; kf[k].center_x = (double)(s >> 8) / 1e6 - 8.0;
+                s = s * 1103515245u + 12345u; kf[k].center_y = (double)(s >> 8) / 1e6 - 8.0;
+                s = s * 1103515245u + 12345u; kf[k].zoom = 1e-12 * (double)((s >> 8) + 1);
+                s = s * 1103515245u + 12345u; kf[k].duration = (float)((s >> 24) % 5);
+            }
+            if (fr_zoom_path_play(z, kf, nk > 6 ? 6 : nk) != FR_OK) return 8;
+            for (int u = 0; u < 40; ++u) {
+                int anim = 0, dirty = 0; float prog = 0.0f;
+                s = s * 1103515245u + 12345u;
+                if (fr_zoom_path_update(z, (float)((s >> 20) % 300) / 100.0f, &st, &anim, &prog, &dirty) != FR_OK) return 9;
+                if (!(st.zoom > 0.0) || prog < 0.0f || prog > 1.0f) return 10;
+            }
+            if ((t & 15) == 0) fr_zoom_path_zoom_to(z, &st, 0.25, -0.5, 1e-9, 3.0f);
+        }
+        fr_zoom_path_free(z);
+    }
     free(buf);
     printf("parsed ok %d, rejected %d\n", ok, bad);
     return (argc >= 3 && ok > 0 && bad > 0) ? 0 : 5;

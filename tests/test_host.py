@@ -536,7 +536,7 @@ def test_hot_kernels_keep_their_register_budget(fr):
 
 
 def test_host_code_under_sanitizers(golden, tmp_path, monkeypatch):
-    """The C host side (fr_host.c, fr_franim.c, fr_frameio.c) built with -fsanitize=address,undefined and with
+    """The C host side (fr_host.c, fr_franim.c, fr_frameio.c, fr_zoompath.c) built with -fsanitize=address,undefined and with
     -fsanitize=thread (CPU builds only: GPU sanitizers are not available on the pool) and driven by
     tests/c_client/fuzz_host.c: truncated and corrupted .franim inputs, interpolation outside the keyframe range,
     save / re-parse, multi-band PNG writes on 8 worker threads."""
@@ -549,6 +549,7 @@ def test_host_code_under_sanitizers(golden, tmp_path, monkeypatch):
         cmd = ["gcc", "-std=c11", "-g", "-O1", *flags, "-fno-omit-frame-pointer",
                "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
                os.path.join(csrc, "fr_host.c"), os.path.join(csrc, "fr_franim.c"), os.path.join(csrc, "fr_frameio.c"),
+               os.path.join(csrc, "fr_zoompath.c"),
                os.path.join(ROOT, "tests", "c_client", "fuzz_host.c"), "-o", exe, "-lm", "-lz", "-lpthread"]
         out = subprocess.run(cmd, capture_output=True, text=True)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -592,3 +593,81 @@ def test_colorize_supported_stops_where_a_float_nu_can_round_up_to_max_iter(fr):
     assert 0.3 < mu < 0.5
     assert np.float32(np.float32(1 << 22) - np.float32(mu)) < np.float32(1 << 22)        # still below: representable
     assert np.float32(np.float32(1 << 24) - np.float32(mu)) == np.float32(1 << 24)       # rounds up: the hazard
+
+
+# ---- deep-zoom zoom paths (src/deep_zoom_system.cpp:454-556) ---------------------------------------------------
+def _zoom_path_model(path, state, steps):
+    """Pure-Python restatement of DeepZoomManager::update_animation + interpolate_to_keyframe (:487-556), float32 time
+    arithmetic as the reference's floats, double centre / zoom: (cx, cy, zoom, animating, progress, orbit_dirty) per step."""
+    import math
+    f32 = np.float32
+    cur, t = 0, f32(0.0)
+    animating, progress = len(path) > 0, f32(0.0)
+    cx, cy, z = state
+    out = []
+    for dt in steps:
+        dirty = False
+        if not path or cur >= len(path):
+            animating = False
+        else:
+            t = f32(t + f32(dt))
+            kx, ky, kz, kd = path[cur]
+            if t >= f32(kd):
+                cx, cy, z = kx, ky, kz
+                cur += 1
+                t = f32(0.0)
+                dirty = True
+                if cur >= len(path):
+                    animating, progress = False, f32(1.0)
+            else:
+                tt = float(f32(t / f32(kd)))
+                if 0 < cur < len(path):
+                    px, py, pz, _ = path[cur - 1]
+                    lz = math.log(pz) + tt * (math.log(kz) - math.log(pz))
+                    cx, cy, z = px + tt * (kx - px), py + tt * (ky - py), math.exp(lz)
+                total = f32(0.0); elapsed = f32(0.0)
+                for i, k in enumerate(path):
+                    total = f32(total + f32(k[3]))
+                    if i < cur:
+                        elapsed = f32(elapsed + f32(k[3]))
+                elapsed = f32(elapsed + t)
+                progress = f32(elapsed / total) if total > 0 else f32(1.0)
+        out.append((cx, cy, z, animating, float(progress), dirty))
+    return out
+
+
+def test_zoom_path_follows_the_reference_state_machine(fr):
+    """zoomTo + update_animation step by step against the restated state machine: the start keyframe (duration 0) is
+    reached at the first update, then centre linear / zoom in log space, the target hit exactly when its duration has
+    passed, zoom_animating / zoom_progress as DeepZoomState reports them."""
+    st = fr.FractalState()                                   # centre (-0.5, 0), zoom 3
+    kf = fr.DeepZoomPath.preset("Seahorse")
+    assert (kf.center_x, kf.center_y, kf.zoom, kf.duration) == (-0.743643887037151, 0.13182590420533, 1e-6, 5.0)
+    assert fr.DeepZoomPath.preset(1).zoom == 1e-8 and fr.DeepZoomPath.preset(2).duration == 10.0
+    z = fr.DeepZoomPath(st)
+    z.zoom_to(kf.center_x, kf.center_y, kf.zoom, kf.duration)
+    assert z.zoom_animating and z.zoom_progress == 0.0
+    steps = [0.016, 1.0, 0.5, 1.25, 2.0, 0.2, 0.1, 0.3]
+    model = _zoom_path_model([(-0.5, 0.0, 3.0, 0.0), (kf.center_x, kf.center_y, kf.zoom, kf.duration)], (-0.5, 0.0, 3.0), steps)
+    for dt, (cx, cy, zoom, anim, prog, dirty) in zip(steps, model):
+        got_dirty = z.update_animation(dt)
+        assert (st.center_x, st.center_y) == (cx, cy) and st.zoom == zoom, (dt, st, (cx, cy, zoom))
+        assert z.zoom_animating == anim and abs(z.zoom_progress - prog) < 1e-7 and got_dirty == dirty
+    assert not z.zoom_animating and z.zoom_progress == 1.0
+    assert (st.center_x, st.center_y, st.zoom) == (kf.center_x, kf.center_y, kf.zoom)      # landed on the target exactly
+    # log-space: half way in time is the geometric mean of the zooms
+    z2 = fr.DeepZoomPath(fr.FractalState(zoom=4.0))
+    z2.play_zoom_path([fr.ZoomKeyframe(0.0, 0.0, 4.0, 0.0), fr.ZoomKeyframe(1.0, -1.0, 1e-4, 2.0), fr.ZoomKeyframe(1.0, -1.0, 1e-2, 1.0)])
+    z2.update_animation(0.0)
+    z2.update_animation(1.0)
+    assert abs(z2.state.zoom - 0.02) < 1e-15 and z2.state.center_x == 0.5 and abs(z2.zoom_progress - 1.0 / 3.0) < 1e-7
+    z2.update_animation(1.0)                                  # reaches keyframe 1
+    z2.update_animation(0.5)                                  # half way to keyframe 2: zoom back out, log space
+    assert abs(z2.state.zoom - 1e-3) < 1e-18 and abs(z2.zoom_progress - 2.5 / 3.0) < 1e-7
+    # an empty path plays nothing; a non-positive zoom is refused (log space)
+    z3 = fr.DeepZoomPath()
+    z3.play_zoom_path([])
+    z3.update_animation(1.0)
+    assert not z3.zoom_animating and z3.state.zoom == 3.0
+    with pytest.raises(fr.FractalRendererError):
+        z3.play_zoom_path([fr.ZoomKeyframe(0, 0, 0.0, 1.0)])
