@@ -567,7 +567,9 @@ def test_bench_workloads_and_cpu_baseline_leg(oracle):
     import bench
     for name, w in bench.WORKLOADS.items():
         assert {"desc", "fractal", "precision", "W", "H", "state"} <= set(w), name
-        assert w["fractal"] in ("Mandelbrot", "JuliaSet") and w["precision"] in ("F64", "F32"), name
+        assert w["fractal"] in ("Mandelbrot", "JuliaSet", "Deep_Zoom") and w["precision"] in ("F64", "F32"), name
+        if "kernel" in w:           # colorize / export entries: one launch of that kernel per step, an HBM roofline
+            assert w["kernel"] in ("colorize", "export8", "export16") and w["bytes_per_pixel"] in (24, 19, 22), name
         assert w["state"]["max_iterations"] >= 1 and w["W"] > 0 and w["H"] > 0
     assert bench.WORKLOADS["c2"]["W"] == bench.WORKLOADS["c2"]["H"] == 4096
     assert bench.WORKLOADS["c2"]["state"] == {"max_iterations": 1024} and bench.WORKLOADS["c2"]["precision"] == "F64"
@@ -575,6 +577,11 @@ def test_bench_workloads_and_cpu_baseline_leg(oracle):
     b = bench.cpu_baseline(w)
     assert b["kind"] == "port" and b["unit"] == "Mpixels/s" and b["cores"] >= 1 and b["value"] > 0
     assert "sample" in b and "oracle" in b["sample"]
+    assert b["single_thread"]["cores"] == 1 and b["single_thread"]["value"] > 0
+    # the Deep_Zoom workload goes through the same leg (fractal 5 of the oracle)
+    wd = dict(bench.WORKLOADS["deepzoom"], W=64, H=48, cpu_rows=48, cpu_passes=1)
+    wd["state"] = dict(wd["state"], max_iterations=200)
+    assert bench.cpu_baseline(wd)["value"] > 0
 
 
 def test_colorize_supported_stops_where_a_float_nu_can_round_up_to_max_iter(fr):
