@@ -60,6 +60,10 @@ struct fr_ctx {
     size_t scratch_bytes;
     uint32_t debug_region_blocks; /* tests only: cap the capacity of a survivor-stream region, to provoke an overflow */
     double2* log2_tab;          /* device copy of the log2 table of the fp64 smooth-count epilogue (log2_tab()) */
+    void* coord_buf;            /* lean tile pass: W + H coordinates of the frame being rendered (prepare_kernel) */
+    size_t coord_bytes;
+    uint32_t tune_tile_kernel;  /* 0 = automatic (the lean tile kernel where it applies), 1 = the general tile_kernel */
+    uint32_t tune_tile_pixels;  /* lean tile kernel: sub-tiles (pixels per lane) per trip, 0 = automatic (2), 1 or 2 */
     uint32_t* overflow_host;    /* pinned, device-mapped word: a survivor stream ran out of blocks (see StreamRef::overflow) */
     uint32_t* overflow_dev;     /* the same word as the kernels address it */
     bool render_on_user_stream; /* the most recent render was enqueued on a caller's stream: ev_end orders the context's
@@ -135,6 +139,7 @@ extern "C" void fr_ctx_destroy(fr_ctx* c)
     (void)hipFree(c->d_ctrl);
     if (c->overflow_host) (void)hipHostFree(c->overflow_host);
     if (c->log2_tab) (void)hipFree(c->log2_tab);
+    if (c->coord_buf) (void)hipFree(c->coord_buf);
     for (int k = 0; k < 2; ++k) if (c->stream_buf[k]) (void)hipFree(c->stream_buf[k]);
     if (c->frame_buf) (void)hipFree(c->frame_buf);
     if (c->orbit_host) (void)hipHostFree(c->orbit_host);
@@ -206,6 +211,12 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         c->tune_stream_probes = (uint32_t)value & 0xFu;
     } else if (!strcmp(name, "stream_rotate")) {
         c->tune_stream_rotate = (uint32_t)value;
+    } else if (!strcmp(name, "tile_kernel")) {
+        if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "tile_kernel must be 0 (automatic: lean where it applies) or 1 (general)");
+        c->tune_tile_kernel = (uint32_t)value;
+    } else if (!strcmp(name, "tile_pixels")) {
+        if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "tile_pixels must be 0 (automatic), 1 or 2");
+        c->tune_tile_pixels = (uint32_t)value;
     } else if (!strcmp(name, "debug_region_blocks")) {
         c->debug_region_blocks = (uint32_t)value;     /* tests only (overflow reporting); 0 = the real capacity */
     } else if (!strcmp(name, "diag_buffer")) {
@@ -297,6 +308,33 @@ static hipError_t launch_tile(int shape, dim3 grid, hipStream_t s, const LaunchA
     }
     return a.aa > 1 ? launch_tile_aa<T, FRACTAL, EFFECTS, true>(shape, grid, s, a)
                     : launch_tile_aa<T, FRACTAL, EFFECTS, false>(shape, grid, s, a);
+}
+
+template <typename T, int FRACTAL>
+static hipError_t launch_tile_lean(int np, dim3 grid, hipStream_t s, const LaunchArgs& a)
+{
+    if (np == 2) {
+        if (a.period_window)
+            hipLaunchKernelGGL((tile_lean_kernel<T, FRACTAL, true, 2>), grid, dim3(kBlockThreads), 0, s, a);
+        else
+            hipLaunchKernelGGL((tile_lean_kernel<T, FRACTAL, false, 2>), grid, dim3(kBlockThreads), 0, s, a);
+    } else {
+        if (a.period_window)
+            hipLaunchKernelGGL((tile_lean_kernel<T, FRACTAL, true, 1>), grid, dim3(kBlockThreads), 0, s, a);
+        else
+            hipLaunchKernelGGL((tile_lean_kernel<T, FRACTAL, false, 1>), grid, dim3(kBlockThreads), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+/* control block + coordinate tables of a lean render (prepare_kernel) */
+template <typename T, int FRACTAL>
+static hipError_t launch_prepare(hipStream_t s, const LaunchArgs& a, uint32_t* ctrl, uint32_t n_ctrl)
+{
+    const uint32_t n = (uint32_t)(a.W + a.H) > n_ctrl ? (uint32_t)(a.W + a.H) : n_ctrl;
+    const dim3 grid((n + kBlockThreads - 1) / kBlockThreads);
+    hipLaunchKernelGGL((prepare_kernel<T, FRACTAL == 0 ? 0 : 1>), grid, dim3(kBlockThreads), 0, s, a, ctrl, n_ctrl);
+    return hipGetLastError();
 }
 
 template <typename T, int FRACTAL>
@@ -493,6 +531,8 @@ static void fill_params(LaunchArgs& a, const fr_params* p)
     fr_palette_table_build(p->fractal_type != FR_FRACTAL_MANDELBROT ? 1 : 0, p->palette_mode, &a.pal);
     a.inv_max_iter = 1.0 / (double)p->max_iterations;
     a.inv_log2_bailout = 1.0 / log2((double)p->bailout);
+    a.inv_max_iter_f = (float)a.inv_max_iter; a.inv_log2_bailout_f = (float)a.inv_log2_bailout;
+    a.color_scale_d = (double)p->color_scale; a.color_offset_d = (double)p->color_offset;
     a.lib_log = !(p->bailout > 1.0f);        /* log2_pos() needs positive arguments: |z|^2 > 1 */
 }
 
@@ -678,6 +718,10 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
                               : (double)(p->bailout * p->bailout);
         const double c2 = a.julia_cx * a.julia_cx + a.julia_cy * a.julia_cy;
         a.fast_ok = (B2 >= 4.5 && B2 <= 1e12 && (!julia || c2 <= B2)) ? 1 : 0;
+        /* 4 bailout^2 as the kernels form it: B * B in the kernel's precision, times 4 (exact) */
+        const float b2f = p->bailout * p->bailout;
+        a.b2x4_d = 4.0 * ((double)p->bailout * (double)p->bailout);
+        a.b2x4_f = 4.0f * b2f;
     }
 
     /* host-prepared reciprocals; the divide-free viewport map is enabled only when verified exact */
@@ -729,10 +773,33 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         if (st != FR_OK) return st;
         if (c->debug_region_blocks && c->debug_region_blocks < region_blocks) region_blocks = c->debug_region_blocks;
     }
+    /* the lean tile kernel: every one-sample render without effects on 8x8 sub-tiles whose row strips (if sharded) are
+     * whole sub-tile rows; "tile_kernel" = 1 keeps the general kernel (tests compare the two bitwise) */
+    const bool pool = !staged && !effects && p->antialiasing_samples <= 1 && c->tune_pool == 2;
+    const bool lean = !effects && p->antialiasing_samples <= 1 && shape == 3 && !pool && !fused && c->tune_tile_kernel != 1u &&
+                      (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
+    if (lean) {
+        const size_t need = ((size_t)W + H) * sizeof(double);
+        if (need > c->coord_bytes) {
+            if (c->coord_buf) { (void)hipFree(c->coord_buf); c->coord_buf = nullptr; }
+            c->coord_bytes = 0;
+            FR_HIP_TRY(hipMalloc(&c->coord_buf, need));
+            c->coord_bytes = need;
+        }
+        a.xs = c->coord_buf;
+        a.yds = (uint8_t*)c->coord_buf + (size_t)W * (f64 ? sizeof(double) : sizeof(float));
+    }
     if (reserve_only) return FR_OK;
 
-    FR_HIP_TRY(clear_control_block(c, stream));
+    /* the frame's device time (fr_ctx_last_kernel_ms) includes the small launch that prepares it */
     FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
+    if (lean) {
+        hipError_t ep = by_variant(fractal, f64, [&](auto t, auto f) {
+            return launch_prepare<decltype(t), decltype(f)::value>(stream, a, c->d_ctrl, (uint32_t)kCtrlWords); });
+        if (ep != hipSuccess) return fr_set_error(FR_ERR_HIP, "prepare kernel launch failed: %s", hipGetErrorString(ep));
+    } else {
+        FR_HIP_TRY(clear_control_block(c, stream));
+    }
 
     /* ---- tile pass ---------------------------------------------------------------------------------- */
     a.q = tq;
@@ -768,7 +835,6 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     }
     a.diag = c->diag;
     hipError_t e;
-    const bool pool = !staged && !effects && p->antialiasing_samples <= 1 && c->tune_pool == 2;
     if (pool) {
         /* lane pool: claims are rare (a run of sub-tiles feeds 64 lanes for many refills) */
         a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 32u;
@@ -787,8 +853,12 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         /* a pass that runs its samples to max_iter closes cycles in escape_run: SSAA (any shape; always compiled in) and
          * the one-sample kernel with 8x8 sub-tiles (its PERIOD instantiation, launch_tile) */
         a.period_window = !staged ? period_window(c) : 0u;          /* a staged tile pass hands its survivors on */
-        e = by_variant(fractal, f64, [&](auto t, auto f) {
-            return launch_tile<decltype(t), decltype(f)::value, false>(shape, dim3(grid), stream, a); });
+        if (lean)
+            e = by_variant(fractal, f64, [&](auto t, auto f) {
+                return launch_tile_lean<decltype(t), decltype(f)::value>(c->tune_tile_pixels == 1u ? 1 : 2, dim3(grid), stream, a); });
+        else
+            e = by_variant(fractal, f64, [&](auto t, auto f) {
+                return launch_tile<decltype(t), decltype(f)::value, false>(shape, dim3(grid), stream, a); });
     }
     if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString(e));
 

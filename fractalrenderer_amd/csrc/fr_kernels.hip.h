@@ -43,6 +43,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "fr_internal.h"
 
 #pragma clang fp contract(off)
@@ -115,6 +116,10 @@ struct LaunchArgs {
     float  aspect_f;             /* (float)W / (float)H   */
     double inv_max_iter;         /* 1 / max_iter (colour stage only) */
     double inv_log2_bailout;     /* 1 / log2(bailout) (Julia smooth count) */
+    /* the same, and the colour knobs, in the precision the kernel reads them in: wave-uniform SGPR operands (a float
+     * widened on the device is a VALU conversion per use, or two more live VGPRs) */
+    float  inv_max_iter_f, inv_log2_bailout_f;
+    double color_scale_d, color_offset_d;
     int32_t lib_log;             /* bailout <= 1: smooth count through the library log(), as written */
     /* stage: this launch runs iterations [i0, i1); i1 < max_iter -> unfinished pixels go to `out` */
     int32_t i0, i1;
@@ -127,9 +132,28 @@ struct LaunchArgs {
     int32_t* iter;
     QueueArgs q;
     const double2* log2_tab;     /* kLog2Entries x {1/m_i, log2 m_i}: see log2_tab() (built on the host, staged into LDS) */
+    /* lean tile pass (tile_lean_kernel): per-column / per-row coordinates of the frame, written by prepare_kernel in
+     * front of every render: xs[px] = Re of the pixel's point, yds[py] = 2 Im of it (T = the render's precision) */
+    void* xs; void* yds;
+    double b2x4_d; float b2x4_f; /* 4 bailout^2 in the kernel's precision */
     uint64_t* diag;              /* optional: 4 words per wave (t_start, t_end, items, dequeues) */
     fr_palette_table pal;
 };
+
+/* The kernel arguments, re-read where they are used.  Everything a persistent kernel reads from its argument block is
+ * loop-invariant, so the optimiser loads it all in front of the main loop -- and then spills what does not fit in the
+ * ~100 SGPRs to VGPR lanes: v_writelane / v_readlane in the hot path, each a VALU issue slot (the general tile kernel
+ * carries 29-48 spilled SGPRs).  A pointer that went through an empty asm statement is a new value every time: loads
+ * through it stay where they are written (s_load from the scalar cache + one wait), and values needed once per run of
+ * sub-tiles or once per 64 survivors stop occupying registers in between.  Valid in kernels whose ONLY parameter is the
+ * LaunchArgs block (it then sits at offset 0 of the kernarg segment). */
+typedef __attribute__((address_space(4))) const LaunchArgs* KArgs;
+__device__ __forceinline__ KArgs kargs()
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (KArgs)p;
+}
 
 /* What one workgroup keeps in LDS: the palette knot table and the viewport constants. */
 struct LdsBlock {
@@ -279,36 +303,46 @@ __device__ __forceinline__ float pow01(float u, float e)
     return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(u));
 }
 
-/* get_palette_color (shaders/mandelbrot.comp:129-141, shaders/julia.comp:162-181), evaluated
- * from the LDS knot table; like the shader's, its first step is t = fract(t). */
-__device__ __forceinline__ void palette_eval(const fr_palette_table& pal, float t, float rgb[3])
+/* get_palette_color (shaders/mandelbrot.comp:129-141, shaders/julia.comp:162-181), evaluated from the knot table;
+ * like the shader's, its first step is t = fract(t).
+ * U = the table in the kernel arguments (wave-uniform: SGPRs), L = its copy in LDS.  Everything that steers control
+ * flow -- warp kind, segment count, break points -- is read from U: read from LDS they are VGPR values, every `if` on
+ * them is compiled as a divergent branch (compare, exec save / restore, skip branch) and the break-point compares
+ * need the loads first (found in the ISA: ~45 VALU + 20 SALU per call).  Only what is indexed by the lane's segment
+ * (its lower break point, factor and two knots) comes from L.
+ * Fire-style ramps return knot[last] on their last segment: mix(a, b, 0) == a exactly (knots are >= 0), so the
+ * factor is forced to 0 there instead of branching. */
+template <class PAL>
+__device__ __forceinline__ void palette_eval(PAL& U, const fr_palette_table& L, float t, float rgb[3])
 {
     const float u = t - floorf(t);
-    const int warp = pal.warp;
+    const int warp = U.warp;
     if (warp == FR_WARP_GRAY) { rgb[0] = rgb[1] = rgb[2] = u; return; }
     float w = u;
     if (warp == FR_WARP_POW) {
-        w = pow01(u, pal.warp_exp);
+        w = pow01(u, U.warp_exp);
     } else if (warp == FR_WARP_SMOOTHSTEP) {
         float s = clamp01((u - 0.0f) / (1.0f - 0.0f));
         w = s * s * (3.0f - 2.0f * s);
     }
     /* cascade "if (w < b1) .. else if (w < b2) .." == count of break points <= w */
+    const int nseg = U.nseg;
     int seg = 0;
-    const int nseg = pal.nseg;
-    for (int k = 1; k < 5; ++k) seg += (k < nseg && !(w < pal.seg_lo[k])) ? 1 : 0;
-    if (pal.last_const && seg == nseg - 1) {
-        rgb[0] = pal.knot[seg][0]; rgb[1] = pal.knot[seg][1]; rgb[2] = pal.knot[seg][2];
-        return;
+#pragma unroll
+    for (int k = 1; k < 5; ++k) {
+        const float lo = k < nseg ? U.seg_lo[k] : __builtin_inff();       /* wave-uniform select */
+        seg += !(w < lo) ? 1 : 0;
     }
-    const float d = w - pal.seg_lo[seg];
-    float k = d * pal.seg_k[seg];
-    if (pal.any_div) {                      /* only julia.comp's cosmic and lava ramps divide (:87-101, :149-163) */
+    const float d = w - L.seg_lo[seg];
+    float k = d * L.seg_k[seg];
+    if (U.any_div) {                        /* only julia.comp's cosmic and lava ramps divide (:87-101, :149-163) */
         cold_path();
-        if (pal.seg_div[seg]) k = d / pal.seg_k[seg];
+        if (L.seg_div[seg]) k = d / L.seg_k[seg];
     }
-    const float* a = pal.knot[seg];
-    const float* b = pal.knot[seg + 1];
+    const int const_seg = U.last_const ? nseg - 1 : 99;                   /* wave-uniform */
+    k = seg == const_seg ? 0.0f : k;
+    const float* a = L.knot[seg];
+    const float* b = L.knot[seg + 1];
     for (int c = 0; c < 3; ++c) rgb[c] = a[c] * (1.0f - k) + b[c] * k;   /* GLSL mix */
 }
 
@@ -346,51 +380,73 @@ __device__ __forceinline__ void post_chain(float rgb[3], float brightness, float
  * Burning Ship: shaders/burning_ship.comp:259-299 (interior style 0 / no accumulators).
  * Shared by the render kernels and by colorize_kernel, so a frame recoloured from its nu plane is
  * bit-identical to the frame the render kernels write. */
-template <typename T, int FRACTAL>
-__device__ __forceinline__ void colour_of(const LaunchArgs& A, const LdsBlock& S, const T nu, const bool interior,
+/* wave-uniform colour-stage constants in the kernel's precision; ARGS is LaunchArgs by reference (general kernels) or
+ * the kernel-argument segment itself (kargs(): re-read at the point of use) */
+template <typename T> struct ArgsOf;
+template <> struct ArgsOf<double> {
+    template <class ARGS> static __device__ __forceinline__ double inv_max_iter(ARGS& a) { return a.inv_max_iter; }
+    template <class ARGS> static __device__ __forceinline__ double inv_log2_bailout(ARGS& a) { return a.inv_log2_bailout; }
+    template <class ARGS> static __device__ __forceinline__ double color_scale(ARGS& a) { return a.color_scale_d; }
+    template <class ARGS> static __device__ __forceinline__ double color_offset(ARGS& a) { return a.color_offset_d; }
+};
+template <> struct ArgsOf<float> {
+    template <class ARGS> static __device__ __forceinline__ float inv_max_iter(ARGS& a) { return a.inv_max_iter_f; }
+    template <class ARGS> static __device__ __forceinline__ float inv_log2_bailout(ARGS& a) { return a.inv_log2_bailout_f; }
+    template <class ARGS> static __device__ __forceinline__ float color_scale(ARGS& a) { return a.color_scale; }
+    template <class ARGS> static __device__ __forceinline__ float color_offset(ARGS& a) { return a.color_offset; }
+};
+
+template <typename T, int FRACTAL, class ARGS>
+__device__ __forceinline__ void colour_of(ARGS& A, const LdsBlock& S, const T nu, const bool interior,
                                           float rgb[3])
 {
-    const T inv_max_iter = (T)A.inv_max_iter;
+    const T inv_max_iter = ArgsOf<T>::inv_max_iter(A);
+    const T color_scale = ArgsOf<T>::color_scale(A), color_offset = ArgsOf<T>::color_offset(A);
     if constexpr (FRACTAL == 0) {
-        T t = nu * inv_max_iter * (T)S.color_scale;                   /* :179 */
+        T t = nu * inv_max_iter * color_scale;                        /* :179 */
         t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
-        if (!(interior && A.interior_style == 1))                     /* :182-183, :190 */
-            palette_eval(S.pal, pal_arg(t + (T)S.color_offset), rgb);
-    } else {
-        if (!interior) {                                              /* :243-244 interior: black */
-            T t = nu * inv_max_iter;
-            t = (T)S.color_offset + t * (T)S.color_scale;
-            palette_eval(S.pal, pal_arg(t), rgb);
+        palette_eval(A.pal, S.pal, pal_arg(t + color_offset), rgb);
+        if (A.interior_style == 1) {                                  /* :182-183, :190 (wave-uniform test) */
+            rgb[0] = interior ? 0.0f : rgb[0]; rgb[1] = interior ? 0.0f : rgb[1]; rgb[2] = interior ? 0.0f : rgb[2];
         }
+    } else {
+        T t = nu * inv_max_iter;
+        t = color_offset + t * color_scale;
+        palette_eval(A.pal, S.pal, pal_arg(t), rgb);
+        rgb[0] = interior ? 0.0f : rgb[0]; rgb[1] = interior ? 0.0f : rgb[1]; rgb[2] = interior ? 0.0f : rgb[2];   /* :243-244 interior: black */
     }
 }
 
 /* Smooth count + colour of one finished sample (no trap/stripe effects).  `it` is the escape
  * index, it >= max_iter for a sample that never escaped.
  * Mandelbrot: shaders/mandelbrot.comp:172-190; Julia: shaders/julia.comp:237-248. */
-template <typename T, int FRACTAL>
-__device__ __forceinline__ void shade(const LaunchArgs& A, const LdsBlock& S, const LogTab<T>& lg, const int it, const T r2,
+template <typename T, int FRACTAL, class ARGS>
+__device__ __forceinline__ void shade(ARGS& A, const LdsBlock& S, const LogTab<T>& lg, const int it, const T r2,
                                       const bool want_nu, const bool want_rgb, T& nu, float rgb[3])
 {
-    const int max_iter = S.max_iter;
+    const int max_iter = A.max_iter;                                  /* wave-uniform */
     nu = T(0);
     rgb[0] = rgb[1] = rgb[2] = 0.0f;
     if (!want_nu) return;
     nu = (T)max_iter;                                                 /* mandelbrot.comp:172, julia.comp:243 */
     if (it < max_iter) {
+        const T i1 = (T)(it + 1);                                     /* == (T)it + 1: integers below 2^24 */
         if constexpr (FRACTAL == 0) {                                 /* :173-177: mu = log2(log2|z|) */
             if (!A.lib_log) {
-                nu = (T)it + T(1) - lg.log2(T(0.5) * lg.log2(r2));
+                nu = i1 - lg.log2(T(0.5) * lg.log2(r2));
             } else {
+                cold_path();
                 const T log_zn = Real<T>::log(r2) / T(2);
                 nu = (T)it + T(1) - Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
             }
         } else {                                                      /* julia.comp:237-248 */
             /* log(log(r2)/log(B))/log 2 == log2(log2(r2) / log2(B)) */
-            if (!A.lib_log)
-                nu = (T)it + T(1) - lg.log2(lg.log2(r2) * (T)A.inv_log2_bailout);
-            else
+            if (!A.lib_log) {
+                nu = i1 - lg.log2(lg.log2(r2) * ArgsOf<T>::inv_log2_bailout(A));
+            } else {
+                cold_path();
                 nu = (T)it + T(1) - Real<T>::log(Real<T>::log(r2) / (T)S.log_bailout) / Real<T>::ln2();
+            }
         }
     }
     if (want_rgb) colour_of<T, FRACTAL>(A, S, nu, it >= max_iter, rgb);
@@ -468,7 +524,7 @@ struct WaveQueue {
     uint32_t n_groups, group;     /* groups dealt round-robin: shard k owns groups k, k+8, ... of `group` items */
     const uint32_t* len_words;    /* or: per-shard lengths in memory (kShardStrideWords apart), capped at len_cap */
     uint32_t len_cap;
-    uint32_t run_shift, run_min, run_max;
+    uint32_t run_shift, run_min, run_max, run_even;
     uint32_t lane;
     uint32_t shard, tried, seen, max_tries;
     uint32_t cur_n, cur_raw;
@@ -487,7 +543,8 @@ struct WaveQueue {
         const uint32_t rem = seen_head < l ? l - seen_head : 0u;
         uint32_t n = rem >> run_shift;
         n = n < run_min ? run_min : n;
-        return n > run_max ? run_max : n;
+        n = n > run_max ? run_max : n;
+        return (n + run_even) & ~run_even;          /* run_even = 1: whole pairs of sub-tiles (lean tile pass, NP = 2) */
     }
     __device__ __forceinline__ uint32_t claim(uint32_t sh, uint32_t n) const
     {
@@ -500,7 +557,7 @@ struct WaveQueue {
     {
         heads = h;
         n_groups = groups; group = group_items; len_words = nullptr; len_cap = 0;
-        run_shift = shift; run_min = rmin; run_max = rmax; lane = ln;
+        run_shift = shift; run_min = rmin; run_max = rmax; run_even = 0u; lane = ln;
         shard = xcc_id(); tried = 0; seen = 0; max_tries = (uint32_t)kShards;
         cur_n = cur_raw = 0;
     }
@@ -1075,7 +1132,7 @@ tile_kernel(const LaunchArgs A)
                             const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
                             writer.append(alive, pixel, (uint32_t)i1, rec);
                         }
-                        if (!alive) shade<T, 0>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
+                        if (!alive) shade<T, 0>(*kargs(), S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                     } else {
                         T ezx, ezy, min_trap;
                         Orbit<T> o;
@@ -1096,12 +1153,12 @@ tile_kernel(const LaunchArgs A)
                             if (A.interior_style == 1) { coloured = true; }
                             else if (A.interior_style == 2) {
                                 const float tf = expf(-(float)min_trap * 6.0f / fmaxf(S.trap_radius, 1e-6f));
-                                palette_eval(S.pal, S.color_offset + tf * 0.3f, rgb);
+                                palette_eval(A.pal, S.pal, S.color_offset + tf * 0.3f, rgb);
                                 coloured = true;
                             }
                         }
                         if (!coloured) {
-                            palette_eval(S.pal, pal_arg(t + (T)S.color_offset), rgb);
+                            palette_eval(A.pal, S.pal, pal_arg(t + (T)S.color_offset), rgb);
                             if (A.trap_enabled) {                             /* :193-198 */
                                 const float r = fmaxf(S.trap_radius, 1e-6f);
                                 const float tf = expf(-(float)min_trap * 4.0f / r);
@@ -1146,11 +1203,11 @@ tile_kernel(const LaunchArgs A)
                                                    outside_mask, A.trap_enabled != 0, (T)S.trap_radius,
                                                    stripes, (T)S.stripe_density, it, r2, min_dist, stripe_sum);
                         if (it < max_iter) {
-                            shade<T, 2>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
+                            shade<T, 2>(*kargs(), S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                             if (A.trap_enabled && want_rgb) {                 /* burning_ship.comp:302-306 */
                                 const float infl = 1.0f - clamp01((float)min_dist * 2.0f);
                                 float tc[3];
-                                palette_eval(S.pal, infl, tc);
+                                palette_eval(A.pal, S.pal, infl, tc);
                                 const float k = infl * 0.3f;
                                 for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] * (1.0f - k) + tc[c] * k;
                             }
@@ -1165,7 +1222,7 @@ tile_kernel(const LaunchArgs A)
                                 t = clamp01((float)Real<T>::sqrt(zx * zx + zy * zy) * 0.5f); gain = 0.4f;
                             }
                             if (gain != 0.0f && want_rgb) {
-                                palette_eval(S.pal, t, rgb);
+                                palette_eval(A.pal, S.pal, t, rgb);
                                 rgb[0] *= gain; rgb[1] *= gain; rgb[2] *= gain;
                             }
                         }
@@ -1192,7 +1249,7 @@ tile_kernel(const LaunchArgs A)
                             for (int k = 0; k < NF; ++k) rec[k] = rec4[k];
                             writer.append(alive, pixel, (uint32_t)i1, rec);
                         }
-                        if (!alive) shade<T, FRACTAL>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
+                        if (!alive) shade<T, FRACTAL>(*kargs(), S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                     }
                 }
                 if (s == 0) { first_nu = nu; first_it = it; }
@@ -1215,6 +1272,420 @@ tile_kernel(const LaunchArgs A)
     }
     if (staged) writer.finish();
     diag_write(A, (uint32_t)lane, diag_t0, diag_items, diag_claims);
+#ifdef FR_STAMP
+    st_acc[1] = writer.st_block;
+#endif
+    FR_STAMP_WRITE(A, lane);
+}
+
+
+/* ---- control block + coordinate tables ---------------------------------------------------------------------------
+ * One small launch in front of every render (replaces clear_words_kernel there): zeroes the queue heads / stream
+ * counters and writes the two coordinate tables of the lean tile pass.  The viewport map is separable -- Re c depends on
+ * the pixel's column only, Im c on its row only -- so the 15 fp64 operations (two conversions, two 3-op quotients, two
+ * multiply-adds, the doubling) every pixel of the tile pass used to spend on it are W + H table entries instead, each
+ * computed by the as-written expression of the shader (true IEEE divides: the exact-division check is not needed here):
+ *   MAP 0  shaders/mandelbrot.comp:149-151   uv = (pix - 0.5 res) / res.y;  c = center + uv * zoom
+ *   MAP 1  shaders/julia.comp:325, :221-225 (= burning_ship.comp:393, :322-325)
+ *                                            uv = pix / res;  p = center + (uv - 0.5) * zoom * (aspect, 1)
+ * T narrows center / zoom as the reference narrows them for its fp32 shaders (src/compute_effect_manager.h:85-90). */
+template <typename T, int MAP>
+__global__ void __launch_bounds__(kBlockThreads)
+prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n_ctrl)
+{
+    const uint32_t stride = gridDim.x * kBlockThreads, first = blockIdx.x * kBlockThreads + threadIdx.x;
+    for (uint32_t i = first; i < n_ctrl; i += stride) ctrl[i] = 0u;
+    T* __restrict__ xs = reinterpret_cast<T*>(A.xs);
+    T* __restrict__ yds = reinterpret_cast<T*>(A.yds);
+    if (!xs) return;
+    const T center_x = (T)A.center_x, center_y = (T)A.center_y, zoom = (T)A.zoom;
+    const T resx = (T)A.W, resy = (T)A.H;
+    const T aspect = sizeof(T) == 8 ? (T)A.aspect_d : (T)A.aspect_f;
+    for (uint32_t i = first; i < (uint32_t)(A.W + A.H); i += stride) {
+        if (i < (uint32_t)A.W) {
+            const int px = (int)i;
+            if constexpr (MAP == 0) {
+                const T uvx = ((T)px - T(0.5) * resx) / resy;
+                xs[px] = center_x + uvx * zoom;
+            } else {
+                const T uvx = (T)px / resx;
+                xs[px] = center_x + (uvx - T(0.5)) * zoom * aspect;
+            }
+        } else {
+            const int py = (int)(i - (uint32_t)A.W);
+            if constexpr (MAP == 0) {
+                const T uvy = ((T)py - T(0.5) * resy) / resy;
+                yds[py] = T(2) * (center_y + uvy * zoom);
+            } else {
+                const T uvy = (T)py / resy;
+                yds[py] = T(2) * (center_y + (uvy - T(0.5)) * zoom);
+            }
+        }
+    }
+}
+
+/* ---- tile pass, lean form ------------------------------------------------------------------------------------------
+ * The default path of every one-sample render without effects (8x8 sub-tiles): same queue, same survivor stream, same
+ * per-lane arithmetic and therefore the same planes, bit for bit, as tile_kernel -- written for the instruction count.
+ * The tile pass is a PER-PIXEL cost (C2: 10 updates per pixel on average, then a smooth count, a palette and a store),
+ * and it is VALU-issue bound: every VALU instruction is ~4.3 cycles of its SIMD whatever its width (tools/ubench2.hip:
+ * only a handful of 32-bit ops run at 2.3), scalar instructions ride along for free as long as they are fewer.  What
+ * tile_kernel spends per 64-pixel sub-tile -- 239 VALU + 138 SALU on C2, 200 VALU on a view where every pixel escapes
+ * at once -- is mostly not arithmetic: SGPR spills (v_readlane / v_writelane are VALU slots), selects and exec-mask
+ * juggling around values that are wave-uniform but were read from LDS, parking moves, the viewport map.  Here:
+ *   - coordinates come from the two tables of prepare_kernel (2 loads instead of 15 fp64 operations per pixel);
+ *   - a finished lane is not parked at z = 0, c = 0 (12 moves per escape event in fp64): its escape threshold becomes
+ *     NaN (one v_or), it iterates on whatever it holds and never compares as escaped again (escape_run_lean);
+ *   - sub-tile indices are advanced incrementally along the run (one division per 16 sub-tiles at most);
+ *   - the colour stage reads its control values from the kernel arguments (palette_eval);
+ *   - a sub-tile that follows one in which no lane escaped starts in unchecked blocks (interior regions: 16 tested
+ *     updates = 32 VALU + 64 SALU less per sub-tile). */
+/* NP samples per lane (NP sub-tiles per wave and trip): the wave-uniform control -- loop counters, branches, exec-mask
+ * handling, argument re-reads -- is paid once per NP x 64 pixels.  Scalar and vector issue hardly overlap in this code
+ * (every few instructions one waits for the other: v_cmp -> branch, exec write -> VALU; measured: VALU and SALU + branch
+ * cycles add up to ~85 % of the pass), so halving the scalar work per pixel is worth as much as removing vector work. */
+template <typename T, int NP, bool ABS, bool PERIOD>
+__device__ __forceinline__ void escape_run_lean(Orbit<T> (&o)[NP], const T B2x4, const int i1, const bool fast_ok, bool fast,
+                                                const bool (&lane_off)[NP], int (&esc_i)[NP], T (&esc_r2x4)[NP],
+                                                uint64_t (&done)[NP], const uint32_t period_window)
+{
+    using Bits = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
+    constexpr Bits kNaNBits = sizeof(T) == 8 ? (Bits)0x7FF8000000000000ull : (Bits)0x7FC00000u;
+    T thr[NP];                                             /* per-lane escape threshold; NaN: the lane is finished */
+    uint64_t all = ~0ull;                                  /* AND of the done masks */
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        esc_i[p] = i1;
+        esc_r2x4[p] = T(0);
+        thr[p] = lane_off[p] ? (T)__builtin_nanf("") : B2x4;
+        done[p] = __builtin_amdgcn_ballot_w64(lane_off[p]);
+        all &= done[p];
+    }
+    int i = 0;                                             /* wave-uniform: SGPR */
+    T refX[NP], refYd[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { refX[p] = __builtin_nan(""); refYd[p] = refX[p]; }
+    uint32_t snap_window = period_window, snap_closed = 1u;
+    const uint32_t snap_cap = period_window > (((uint32_t)i1 >> 7) << 4) ? period_window : (((uint32_t)i1 >> 7) << 4);
+    int next_snap = 0;
+    auto finish = [&](T& t) { Bits b; __builtin_memcpy(&b, &t, sizeof(T)); b |= kNaNBits; __builtin_memcpy(&t, &b, sizeof(T)); };
+    /* PERIOD: see escape_run; a lane back at its own snapshot never escapes -> finished as "alive at i1" */
+    auto close_cycles = [&]() {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const bool hit = o[p].X == refX[p] && o[p].Yd == refYd[p];
+            const uint64_t hm = __builtin_amdgcn_ballot_w64(hit) & ~done[p];     /* finished lanes hold garbage */
+            if (hm != 0ull) {
+                if (hit) finish(thr[p]);
+                done[p] |= hm;
+                snap_closed += (uint32_t)__builtin_popcountll(hm);
+            }
+        }
+        if (i >= next_snap) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { refX[p] = o[p].X; refYd[p] = o[p].Yd; }
+            if (snap_closed == 0u && snap_window < snap_cap) snap_window <<= 1;
+            snap_closed = 0u;
+            next_snap = i + (int)snap_window;
+        }
+        all = ~0ull;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) all &= done[p];
+    };
+    while (i < i1) {
+        if (all == ~0ull) break;                           /* every lane finished: wave-uniform early-out */
+        const int left = i1 - i;
+        if (fast && left >= kFastBlock) {
+            Orbit<T> snap[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) snap[p] = o[p];
+#pragma unroll
+            for (int k = 0; k < kFastBlock; ++k) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) orbit_step<T, ABS>(o[p]);
+            }
+            uint64_t badm = 0ull;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) badm |= __builtin_amdgcn_ballot_w64(!(orbit_r2x4(o[p]) <= B2x4)) & ~done[p];
+            if (badm == 0ull) {
+                i += kFastBlock;
+                if constexpr (PERIOD) { if (period_window) close_cycles(); }
+                continue;
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) o[p] = snap[p];   /* roll back, replay tested */
+            fast = false;
+        }
+        int end = i + (left < kFastBlock ? left : kFastBlock);
+        bool event = false;
+        do {
+            T r2x4[NP];
+            bool e[NP];
+            uint64_t em = 0ull;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                orbit_step<T, ABS>(o[p]);
+                r2x4[p] = orbit_r2x4(o[p]);
+                e[p] = r2x4[p] > thr[p];                   /* false for ever once thr is NaN */
+                em |= __builtin_amdgcn_ballot_w64(e[p]);
+            }
+            if (em != 0ull) {
+                all = ~0ull;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if (e[p]) { esc_i[p] = i; esc_r2x4[p] = r2x4[p]; finish(thr[p]); }
+                    done[p] |= __builtin_amdgcn_ballot_w64(e[p]);
+                    all &= done[p];
+                }
+                event = true;
+                if (all == ~0ull) end = i;                 /* single-exit loop: this was the last update */
+            }
+            ++i;
+        } while (i < end);
+        if (all == ~0ull) break;
+        fast = fast_ok && !event;
+        if constexpr (PERIOD) { if (period_window) close_cycles(); }
+    }
+}
+
+/* WaveQueue with only its three words of state kept between calls (home shard, shards tried, head last seen) */
+struct LeanQueue {
+    uint32_t shard, tried, seen;
+    __device__ __forceinline__ void init()
+    {
+        KArgs K = kargs();
+        const uint32_t p = (K->q.flags >> kQueueProbeShift) & 0xFu;
+        shard = (p == 0u || p >= (uint32_t)kShards) ? xcc_id() : (blockIdx.x & (uint32_t)(kShards - 1));
+        tried = 0; seen = 0;
+    }
+    __device__ __forceinline__ bool next(uint32_t lane, uint32_t& begin, uint32_t& count, uint32_t& sh, uint32_t even = 0u)
+    {
+        KArgs K = kargs();
+        WaveQueue q;
+        q.init(K->q.heads, K->q.n_blk, (uint32_t)kShardBlock, K->q.run_shift, K->q.run_min, K->q.run_max, lane);
+        q.run_even = even;
+        const uint32_t p = (K->q.flags >> kQueueProbeShift) & 0xFu;
+        if (p != 0u && p < (uint32_t)kShards) q.max_tries = p;
+        q.shard = shard; q.tried = tried; q.seen = seen;
+        const bool got = q.next(begin, count, sh);
+        shard = q.shard; tried = q.tried; seen = q.seen;
+        return got;
+    }
+};
+
+/* RingWriter with the stream description re-read from the kernel arguments at every block (once per 64 survivors) */
+template <typename T, int NF>
+struct LeanWriter {
+    uint32_t head, tail, home;
+#ifdef FR_STAMP
+    uint64_t st_block = 0;
+#endif
+    __device__ __forceinline__ void init() { head = tail = 0; home = xcc_id(); }
+    __device__ __forceinline__ void write_block(WaveRing<T, NF>* ring, uint32_t lane, uint32_t nvalid)
+    {
+        KArgs K = kargs();
+        RingWriter<T, NF> w;
+        w.ring = ring; w.lane = lane;
+        w.out.base = K->out.base; w.out.n_blocks = K->out.n_blocks; w.out.region_blocks = K->out.region_blocks;
+        w.out.rotate = K->out.rotate; w.out.overflow = K->out.overflow; w.head = head; w.tail = tail; w.home = home;
+        w.write_block(nvalid);
+        head = w.head; home = w.home;
+#ifdef FR_STAMP
+        st_block += w.st_block;
+#endif
+    }
+    __device__ __forceinline__ void append(WaveRing<T, NF>* ring, uint32_t lane, bool keep, uint32_t pixel, uint32_t done, const T (&v)[NF])
+    {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        if (m == 0ull) return;
+        if (keep) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t slot = (tail + rank) & (kRingSlots - 1);
+            ring->pix[slot] = pixel;
+            ring->it[slot] = done;
+#pragma unroll
+            for (int k = 0; k < NF; ++k) ring->f[k][slot] = v[k];
+        }
+        tail += (uint32_t)__builtin_popcountll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (tail - head >= 64u) write_block(ring, lane, 64u);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void finish(WaveRing<T, NF>* ring, uint32_t lane)
+    {
+        const uint32_t left = tail - head;
+        if (left > 0u) write_block(ring, lane, left);
+    }
+};
+
+/* NP = 1: one 8x8 sub-tile per trip.  NP = 2: two horizontally adjacent ones (a 16x8 patch, lane (lx, ly) holds the
+ * pixels (lx, ly) and (lx + 8, ly)); a trip whose second sub-tile does not exist (odd run, end of a row) runs with those
+ * samples switched off like lanes outside the frame. */
+template <typename T, int FRACTAL, bool PERIOD, int NP>
+__global__ void __launch_bounds__(kBlockThreads)
+tile_lean_kernel(const LaunchArgs A)
+{
+    constexpr int NF = RecFields<FRACTAL>::n;
+    constexpr bool ABS = Form<FRACTAL>::abs_step;
+
+    __shared__ LdsBlock S;
+    __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
+    stage_constants(S, A);
+    __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
+    const LogTab<T> lg = stage_log2<T>(log2_lds, A);
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    WaveRing<T, NF>* const ring = &rings[threadIdx.x >> 6];
+    const int max_iter = A.max_iter, i1 = A.i1;
+    const bool staged = i1 < max_iter;                       /* survivors continue in the lane pool */
+    const bool fast_ok = A.fast_ok != 0;
+    const T B2x4 = sizeof(T) == 8 ? (T)A.b2x4_d : (T)A.b2x4_f;
+    const bool want_rgb = A.rgba != nullptr;
+    const bool want_nu = want_rgb || A.nu != nullptr;
+    const T* __restrict__ xs = reinterpret_cast<const T*>(A.xs);
+    const T* __restrict__ yds = reinterpret_cast<const T*>(A.yds);
+    const uint32_t W = (uint32_t)A.W, rows_local = (uint32_t)A.rows_local, nsx = A.q.nsx;
+
+    LeanWriter<T, NF> writer;
+    writer.init();
+    LeanQueue q;
+    q.init();
+
+    uint64_t diag_t0 = 0;
+    uint32_t diag_items = 0, diag_claims = 0;
+    if (kargs()->diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
+
+    /* frame row of the first row of sub-tile row sty (row strips dealt round-robin to parts; the host sends sharded
+     * frames here only when a strip is a whole number of sub-tile rows) */
+    auto first_row = [&](uint32_t sty) -> uint32_t {
+        const uint32_t lrow0 = sty * 8u;
+        KArgs K = kargs();
+        if (K->nparts == 1) return lrow0;
+        const uint32_t R = (uint32_t)K->rows_per_strip, strip = lrow0 / R;
+        return (strip * (uint32_t)K->nparts + (uint32_t)K->part) * R + (lrow0 - strip * R);
+    };
+
+    uint32_t begin, count, cur_shard;
+    FR_STAMP_DECL
+    for (;;) {
+        FR_STAMP_BEGIN();
+        const bool got_run = q.next(lane, begin, count, cur_shard, NP == 2 ? 1u : 0u);
+        FR_STAMP_END(0);
+        if (!got_run) break;
+        ++diag_claims;
+        diag_items += count;
+        /* the run, block by block (blocks of 16 consecutive sub-tiles are dealt round-robin to the shards); everything
+         * here is wave-uniform: SALU */
+        uint32_t j = begin;
+        const uint32_t jend = begin + count;
+        while (j < jend) {
+            uint32_t n, sid, stx, sty;
+            {
+                KArgs K = kargs();
+                const uint32_t blk = (j / kShardBlock) * kShards + cur_shard;
+                if (blk >= K->q.n_blk) break;
+                uint32_t jb = (j | (uint32_t)(kShardBlock - 1)) + 1u;
+                jb = jb < jend ? jb : jend;
+                sid = blk * kShardBlock + (j % kShardBlock);
+                n = jb - j;
+                j = jb;
+                const uint32_t n_items = K->q.n_items;
+                if (sid >= n_items) break;
+                n = sid + n > n_items ? n_items - sid : n;
+                sty = K->q.nsx_shift >= 0 ? sid >> K->q.nsx_shift : sid / nsx;
+                stx = sid - sty * nsx;
+            }
+            uint32_t py0 = first_row(sty);
+            bool hint_fast = false;                          /* the previous trip lost no lane: start unchecked */
+            do {
+                /* sub-tiles of this trip: stx .. stx + np - 1 of row sty */
+                uint32_t np = n < (uint32_t)NP ? n : (uint32_t)NP;
+                np = stx + np > nsx ? nsx - stx : np;
+                const uint32_t lrow = sty * 8u + ly;
+                const bool row_in = lrow < rows_local;
+                const T tyd = yds[row_in ? py0 + ly : 0u];     /* table reads: lanes outside the frame read entry 0 */
+                uint32_t pixel[NP];
+                bool inside[NP], lane_off[NP];
+                Orbit<T> o[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const uint32_t px = (stx + (uint32_t)p) * 8u + lx;
+                    inside[p] = (uint32_t)p < np && px < W && row_in;
+                    lane_off[p] = !inside[p];
+                    pixel[p] = lrow * W + px;
+                    const T tx = xs[inside[p] ? px : 0u];
+                    if constexpr (FRACTAL == 1) {
+                        o[p].X = tx; o[p].Yd = tyd;
+                        o[p].cx = (T)S.julia_cx; o[p].cyd = T(2) * (T)S.julia_cy;
+                    } else {
+                        o[p].X = T(0); o[p].Yd = T(0);
+                        o[p].cx = tx; o[p].cyd = tyd;
+                    }
+                    o[p].x2 = o[p].X * o[p].X;
+                    o[p].y2d = o[p].Yd * o[p].Yd;
+                }
+
+                int it[NP];
+                T r2x4[NP];
+                uint64_t done[NP];
+                escape_run_lean<T, NP, ABS, PERIOD>(o, B2x4, i1, fast_ok, hint_fast && fast_ok, lane_off, it, r2x4, done,
+                                                    PERIOD ? A.period_window : 0u);
+                bool lost = false, need_any = false;
+                bool alive[NP], need[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    lost = lost || done[p] != __builtin_amdgcn_ballot_w64(lane_off[p]);
+                    alive[p] = staged && inside[p] && it[p] >= i1;
+                    need[p] = inside[p] && !alive[p];
+                    need_any = need_any || __builtin_amdgcn_ballot_w64(need[p]) != 0ull;
+                }
+                hint_fast = !lost;
+                if (staged) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const T rec4[4] = {o[p].X, o[p].Yd, o[p].cx, o[p].cyd};
+                        T rec[NF];
+                        for (int k = 0; k < NF; ++k) rec[k] = rec4[k];
+                        writer.append(ring, lane, alive[p], pixel[p], (uint32_t)i1, rec);
+                    }
+                }
+                if (need_any) {
+                    /* every lane runs the colour stage of all its samples (what a lane without a finished sample
+                     * computes is dropped): one pass through its wave-uniform branches for NP x 64 pixels */
+                    KArgs K = kargs();
+                    T nu[NP];
+                    float rgb[NP][3];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        shade<T, FRACTAL>(*K, S, lg, it[p], T(0.25) * r2x4[p], want_nu, want_rgb, nu[p], rgb[p]);
+                        if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
+                            post_chain(rgb[p], S.brightness, S.saturation, S.contrast, FRACTAL != 0);
+                    }
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        if (need[p]) {
+                            if (K->rgba) K->rgba[pixel[p]] = make_float4(rgb[p][0], rgb[p][1], rgb[p][2], 1.0f);
+                            if (K->nu) reinterpret_cast<T*>(K->nu)[pixel[p]] = nu[p];
+                            if (K->iter) K->iter[pixel[p]] = it[p];
+                        }
+                    }
+                }
+                stx += np;
+                n -= np;
+                if (stx == nsx) { stx = 0; ++sty; py0 = first_row(sty); hint_fast = false; }
+            } while (n != 0u);
+        }
+    }
+    if (staged) writer.finish(ring, lane);
+    {
+        KArgs K = kargs();
+        if (K->diag && lane == 0) {      /* diagnostics: per-wave timeline (100 MHz ticks) and work counts */
+            const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+            uint64_t* d = K->diag + (size_t)wave_id * kDiagWords;
+            d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = diag_items; d[3] = diag_claims;
+        }
+    }
 #ifdef FR_STAMP
     st_acc[1] = writer.st_block;
 #endif
@@ -1313,7 +1784,7 @@ stream_kernel(const LaunchArgs A)
             if (valid && !alive) {
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
+                shade<T, FRACTAL>(*kargs(), S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
@@ -1476,7 +1947,7 @@ pool_kernel(const LaunchArgs A)
             if (fin != 0u) {
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(A, S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
+                shade<T, FRACTAL>(*kargs(), S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
@@ -1943,7 +2414,7 @@ fused_kernel(const LaunchArgs A)
             if (fin != 0u) {
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(A, S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
+                shade<T, FRACTAL>(*kargs(), S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
@@ -2049,7 +2520,7 @@ fused_kernel(const LaunchArgs A)
             if (inside && !alive) {
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(A, S, lg, it, r2, want_nu, want_rgb, nu, rgb);
+                shade<T, FRACTAL>(*kargs(), S, lg, it, r2, want_nu, want_rgb, nu, rgb);
                 if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
                 if (A.rgba) A.rgba[tpixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
