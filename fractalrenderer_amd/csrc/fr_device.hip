@@ -21,7 +21,8 @@ using namespace fr;
 
 static constexpr int kMaxStages = 16;
 static constexpr uint32_t kAutoStaging = 3u;   /* "staging" = 0: tile pass + lane-pool pass (4, the fused launch, measured slower on whole frames) */
-static constexpr size_t kCtrlWords = (size_t)2 * kMaxStages * kShards * kShardStrideWords;
+static constexpr size_t kStageWords = (size_t)2 * kMaxShards * kShardStrideWords;   /* one stage: its queue heads, then its stream counters */
+static constexpr size_t kCtrlWords = (size_t)kMaxStages * kStageWords;
 
 struct fr_ctx {
     int device;
@@ -63,6 +64,8 @@ struct fr_ctx {
     void* coord_buf;            /* lean tile pass: W + H coordinates of the frame being rendered (prepare_kernel) */
     size_t coord_bytes;
     uint32_t tune_tile_kernel;  /* 0 = automatic (the lean tile kernel where it applies), 1 = the general tile_kernel */
+    uint32_t tune_shards;       /* 0 = automatic, 8 or 64: queue shards / stream regions of a render */
+    uint32_t tune_regions;      /* 0 = automatic (= shards), 8 or 64: regions of the survivor streams */
     uint32_t tune_tile_pixels;  /* lean tile kernel: sub-tiles (pixels per lane) per trip, 0 = automatic (2), 1 or 2 */
     uint32_t* overflow_host;    /* pinned, device-mapped word: a survivor stream ran out of blocks (see StreamRef::overflow) */
     uint32_t* overflow_dev;     /* the same word as the kernels address it */
@@ -214,6 +217,12 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "tile_kernel")) {
         if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "tile_kernel must be 0 (automatic: lean where it applies) or 1 (general)");
         c->tune_tile_kernel = (uint32_t)value;
+    } else if (!strcmp(name, "shards")) {
+        if (value != 0 && value != 8 && value != 64) return fr_set_error(FR_ERR_INVALID_ARG, "shards must be 0 (automatic), 8 or 64");
+        c->tune_shards = (uint32_t)value;
+    } else if (!strcmp(name, "regions")) {
+        if (value != 0 && value != 8 && value != 64) return fr_set_error(FR_ERR_INVALID_ARG, "regions must be 0 (automatic), 8 or 64");
+        c->tune_regions = (uint32_t)value;
     } else if (!strcmp(name, "tile_pixels")) {
         if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "tile_pixels must be 0 (automatic), 1 or 2");
         c->tune_tile_pixels = (uint32_t)value;
@@ -397,8 +406,8 @@ static uint32_t ceil_log2(uint32_t v)
 /* control block in device memory, zeroed by ONE memset per render:
  *   words [s * 256, s * 256 + 256): the 8 queue heads of stage s (128 B apart)
  *   words [(kMaxStages + s) * 256, +256): the 8 region counters of the survivor stream written by stage s */
-static uint32_t* stage_heads(fr_ctx* c, int s) { return c->d_ctrl + (size_t)s * kShards * kShardStrideWords; }
-static uint32_t* stage_counter(fr_ctx* c, int s) { return c->d_ctrl + (size_t)(kMaxStages + s) * kShards * kShardStrideWords; }
+static uint32_t* stage_heads(fr_ctx* c, int s) { return c->d_ctrl + (size_t)s * kStageWords; }
+static uint32_t* stage_counter(fr_ctx* c, int s) { return c->d_ctrl + (size_t)s * kStageWords + (size_t)kMaxShards * kShardStrideWords; }
 
 /* A survivor stream that ran out of blocks (StreamRef::overflow) loses pixels: report it as a failed render at the
  * next point where the host knows the kernels are done.  Sticky until reported. */
@@ -422,9 +431,10 @@ static uint32_t period_window(const fr_ctx* c)
 }
 
 /* zero the queue heads and stream counters of the next render (a kernel, not a memset node: see clear_words_kernel) */
-static hipError_t clear_control_block(fr_ctx* c, hipStream_t stream)
+static hipError_t clear_control_block(fr_ctx* c, hipStream_t stream, int nstages)
 {
-    hipLaunchKernelGGL(clear_words_kernel, dim3(4), dim3(kBlockThreads), 0, stream, c->d_ctrl, (uint32_t)kCtrlWords);
+    const uint32_t n = (uint32_t)((size_t)nstages * kStageWords);
+    hipLaunchKernelGGL(clear_words_kernel, dim3((n + 4 * kBlockThreads - 1) / (4 * kBlockThreads)), dim3(kBlockThreads), 0, stream, c->d_ctrl, n);
     return hipGetLastError();
 }
 
@@ -495,11 +505,11 @@ static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t
     const uint32_t max_grid = (q.n_items + 7) / 8;           /* a wave takes at least 2 sub-tiles per dequeue */
     if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
     q.run_shift = ceil_log2(16u * ((grid * 4u + kShards - 1) / kShards));
-    q.run_min = 2; q.run_max = 8; q.flags = 0;
+    q.run_min = 2; q.run_max = 8; q.flags = 0; q.ns_log2 = 3;
     c->last_grid = grid;
     c->last_stages = 1;
 
-    FR_HIP_TRY(clear_control_block(c, stream));
+    FR_HIP_TRY(clear_control_block(c, stream, 1));
     FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
     hipLaunchKernelGGL((deep_zoom_kernel<3>), dim3(grid), dim3(kBlockThreads), 0, stream, a);
     hipError_t e = hipGetLastError();
@@ -577,7 +587,14 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
     const uint32_t per_wave = c->tune_run_min ? c->tune_run_min : (bounded ? 4u : 2u);
     const uint32_t max_grid = (tq.n_items + 4u * per_wave - 1u) / (4u * per_wave);
     if (grid > max_grid) grid = max_grid < 1 ? 1 : max_grid;
-    const uint32_t waves_per_shard = (grid * 4u + kShards - 1) / kShards;
+    /* Shards: 64 (8 per XCD) where waves stop at their home shard(s) and the frame has work for them -- 64 queue heads
+     * (and 64 block counters of the survivor stream) instead of 8 take the same claims at 8x the rate (kMaxShards);
+     * launches with unlimited stealing keep 8: a wave probes every shard before it exits. */
+    const bool limited = (bounded || moderate) && grid >= 64u;
+    uint32_t ns = (limited && grid >= 512u && tq.n_blk >= 8u * (uint32_t)kMaxShards) ? (uint32_t)kMaxShards : (uint32_t)kShards;
+    if (c->tune_shards) ns = c->tune_shards;
+    tq.ns_log2 = ns == (uint32_t)kMaxShards ? 6u : 3u;
+    const uint32_t waves_per_shard = (grid * 4u + ns - 1) / ns;
     auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
     /* Run length of a dequeue = clamp(remaining >> run_shift, run_min, run_max).
      *  - unbounded items (single pass, measured on C2, profiles/r01_sweep_c2.txt): sub-tile cost varies 100x,
@@ -602,8 +619,9 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
      * passes keep full stealing; so do grids with fewer workgroups than shards. */
     /* Passes whose items are long (SSAA: aa^2 samples to max_iter per pixel; effects; a forced single pass) keep full
      * stealing: with home + one neighbour the C5 view at 2x2 samples takes 9.96 ms instead of 8.12 ms. */
-    uint32_t probes = c->tune_probes ? c->tune_probes : (((bounded || moderate) && grid >= 64u) ? 1u : 0u);
-    if (grid < (uint32_t)kShards) probes = 0;
+    /* 64 shards: home + the next one of the same XCD (80 waves per shard: a second look evens out the ends) */
+    uint32_t probes = c->tune_probes ? c->tune_probes : (limited ? (ns == (uint32_t)kMaxShards ? 2u : 1u) : 0u);
+    if (grid < ns) probes = 0;
     tq.flags |= probes << kQueueProbeShift;
     *grid_out = grid;
     *waves_per_shard_out = waves_per_shard;
@@ -658,12 +676,12 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t
  * one stream; the second buffer only exists for schedules with three or more passes (4 GB less scratch
  * per context at 8192^2 fp64). */
 static int reserve_streams(fr_ctx* c, size_t npx, size_t nfields, bool f64, uint32_t writer_workgroups, int nbuffers,
-                           uint32_t* region_blocks)
+                           uint32_t nregions, uint32_t* region_blocks)
 {
     const size_t block_bytes = 2 * 64 * 4 + nfields * 64 * (f64 ? 8 : 4);
     const uint32_t worst_blocks = (uint32_t)((npx + 63) / 64) + writer_workgroups * 4u + 16u;
-    *region_blocks = (worst_blocks * 3u / 2u + kShards - 1) / kShards + 1u;
-    const size_t need = (size_t)*region_blocks * kShards * block_bytes;
+    *region_blocks = (worst_blocks * 3u / 2u + nregions - 1) / nregions + 1u;
+    const size_t need = (size_t)*region_blocks * nregions * block_bytes;
     for (int k = 0; k < nbuffers; ++k) {
         if (need <= c->stream_bytes[k]) continue;
         if (c->stream_buf[k]) { (void)hipFree(c->stream_buf[k]); c->stream_buf[k] = nullptr; }
@@ -766,10 +784,13 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         const uint32_t cap = (tq.n_items + 31u) / 32u;
         if (sgrid > cap) sgrid = cap < 1u ? 1u : cap;
     }
+    /* the survivor streams have as many regions as the tile queue has shards ("regions" overrides) */
+    const uint32_t nregions = c->tune_regions ? c->tune_regions : (1u << tq.ns_log2);
+    const uint32_t nregions_log2 = nregions == (uint32_t)kMaxShards ? 6u : 3u;
     uint32_t region_blocks = 0;
     if (staged && !fused) {
         const int st = reserve_streams(c, (size_t)rows_local * W, julia ? 2 : 4, f64, grid > sgrid ? grid : sgrid,
-                                       nstage > 2 ? 2 : 1, &region_blocks);
+                                       nstage > 2 ? 2 : 1, nregions, &region_blocks);
         if (st != FR_OK) return st;
         if (c->debug_region_blocks && c->debug_region_blocks < region_blocks) region_blocks = c->debug_region_blocks;
     }
@@ -795,10 +816,10 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
     if (lean) {
         hipError_t ep = by_variant(fractal, f64, [&](auto t, auto f) {
-            return launch_prepare<decltype(t), decltype(f)::value>(stream, a, c->d_ctrl, (uint32_t)kCtrlWords); });
+            return launch_prepare<decltype(t), decltype(f)::value>(stream, a, c->d_ctrl, (uint32_t)((size_t)nstage * kStageWords)); });
         if (ep != hipSuccess) return fr_set_error(FR_ERR_HIP, "prepare kernel launch failed: %s", hipGetErrorString(ep));
     } else {
-        FR_HIP_TRY(clear_control_block(c, stream));
+        FR_HIP_TRY(clear_control_block(c, stream, nstage));
     }
 
     /* ---- tile pass ---------------------------------------------------------------------------------- */
@@ -831,6 +852,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.out.n_blocks = stage_counter(c, 0);
         a.out.region_blocks = region_blocks;
         a.out.rotate = rotate_regions;
+        a.out.nregions = nregions;
         a.out.overflow = c->overflow_dev;
     }
     a.diag = c->diag;
@@ -869,6 +891,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.in.base = (uint8_t*)c->stream_buf[(k - 1) & 1];
         a.in.n_blocks = stage_counter(c, k - 1);
         a.in.region_blocks = region_blocks;
+        a.in.nregions = nregions;
+        a.out.nregions = nregions;
         a.out.base = (uint8_t*)c->stream_buf[k & 1];
         a.out.n_blocks = stage_counter(c, k);
         a.out.region_blocks = region_blocks;
@@ -876,15 +900,16 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.out.overflow = c->overflow_dev;
         memset(&a.q, 0, sizeof(a.q));
         a.q.heads = stage_heads(c, k);
+        a.q.ns_log2 = nregions_log2;                            /* region r of the input stream is shard r of this queue */
         /* a block of 64 records costs at most (i1 - i0) iterations: uniform, claim a few at a time */
-        const uint32_t swps = (sgrid * 4u + kShards - 1) / kShards;
+        const uint32_t swps = (sgrid * 4u + nregions - 1) / nregions;
         a.q.run_shift = clamp_shift((int)ceil_log2(2u * swps));
         a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 16u;
         a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 2u;
         if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
         {
             uint32_t probes = c->tune_stream_probes ? c->tune_stream_probes : (rotate_regions ? 4u : 0u);
-            if (sgrid < 64u) probes = 0;
+            if (sgrid < 64u || sgrid < nregions) probes = 0;
             a.q.flags = probes << kQueueProbeShift;
         }
         a.diag = c->diag ? c->diag + (size_t)k * c->diag_stride : nullptr;

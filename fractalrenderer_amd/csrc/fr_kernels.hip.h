@@ -53,7 +53,14 @@ namespace fr {
 constexpr int kWave = 64;
 constexpr int kBlockThreads = 256;
 constexpr int kWavesPerBlock = kBlockThreads / kWave;
-constexpr int kShards = 8;               /* one queue head per XCD                        */
+constexpr int kShards = 8;               /* XCDs: the smallest number of queue shards / stream regions             */
+constexpr int kMaxShards = 64;           /* the largest: 8 per XCD.  A queue head (a stream's block counter) is ONE word that
+                                          * every wave of its shard updates with a returning atomic, and same-address atomics
+                                          * complete ~15 ns apart: 8 heads serve 0.5 G claims/s.  The staged tile pass makes 37 k
+                                          * queue claims + 47 k block claims per C2 frame, the pool pass of C3 29 k in 0.2 ms with
+                                          * 768 waves asking one word at once when it starts (first claim: 6 us); with 64 heads
+                                          * the same traffic meets 8x the service rate.  Launches with unlimited stealing keep 8
+                                          * (a wave probes every shard before it exits).                                      */
 constexpr int kShardStrideWords = 32;    /* 128 B between heads                            */
 constexpr int kShardBlock = 16;          /* sub-tiles are dealt to shards in blocks of 16  */
 constexpr int kFastBlock = 16;           /* iterations per unchecked block                 */
@@ -70,7 +77,8 @@ struct StreamRef {
     uint32_t region_blocks;      /* capacity of one region; 8 regions hold 1.5x the worst-case total */
     uint32_t rotate;             /* writers move to the next region after every block: equal-length regions
                                   * with the same mix of light and heavy blocks (the reader then needs no stealing) */
-    uint32_t* overflow;          /* host-mapped word of the context: set when all 8 regions were found full (the host
+    uint32_t nregions;           /* kShards or kMaxShards (a power of two) */
+    uint32_t* overflow;          /* host-mapped word of the context: set when all regions were found full (the host
                                   * sizes them for 1.5x the worst case, so this means a sizing bug) -- the records of that
                                   * block are lost and the render is reported as failed, never silently incomplete */
 };
@@ -85,6 +93,7 @@ struct QueueArgs {
     uint32_t run_shift;          /* run length = clamp(remaining >> run_shift, run_min, run_max) */
     uint32_t run_max, run_min;
     uint32_t flags;              /* bits 4-7: probe limit (kQueueProbeShift) */
+    uint32_t ns_log2;            /* log2 of the number of shards: 3 (kShards) or 6 (kMaxShards) */
 };
 
 /* Kernel argument block (passed by value; lands in SGPRs / the scalar cache). */
@@ -525,6 +534,7 @@ struct WaveQueue {
     const uint32_t* len_words;    /* or: per-shard lengths in memory (kShardStrideWords apart), capped at len_cap */
     uint32_t len_cap;
     uint32_t run_shift, run_min, run_max, run_even;
+    uint32_t ns, ns_log2;         /* shards (8 or 64) */
     uint32_t lane;
     uint32_t shard, tried, seen, max_tries;
     uint32_t cur_n, cur_raw;
@@ -535,7 +545,8 @@ struct WaveQueue {
             const uint32_t v = len_words[sh * kShardStrideWords];      /* uniform address: scalar load */
             return v < len_cap ? v : len_cap;
         }
-        return ((n_groups + (uint32_t)kShards - 1u - sh) / (uint32_t)kShards) * group;
+        (void)sh;                  /* every shard owns one block per round of ns blocks (see block_of); the last round may be short */
+        return ((n_groups + ns - 1u) >> ns_log2) * group;
     }
     __device__ __forceinline__ uint32_t run_len(uint32_t sh, uint32_t seen_head) const
     {
@@ -552,19 +563,33 @@ struct WaveQueue {
         if (lane == 0) v = atomicAdd(&heads[sh * kShardStrideWords], n);
         return v;
     }
-    __device__ __forceinline__ void init(uint32_t* h, uint32_t groups, uint32_t group_items, uint32_t shift,
-                                         uint32_t rmin, uint32_t rmax, uint32_t ln)
+    /* Shard-local block index jb of shard sh -> block of the frame.  Round jb of the deal covers blocks [jb ns, (jb+1) ns);
+     * the shard's place in it ROTATES with the round: with a fixed place shard s of 64 would own the same 128-pixel column
+     * stripe of every other sub-tile row (32 blocks per row at 4096 pixels) -- a stripe through the set costs several times
+     * one at the frame's edge, and waves that stop at their home shard cannot level that out (measured: C3 tile pass
+     * 134 -> 157 us with 64 fixed-place shards).  Rotating, every shard visits every column. */
+    static __device__ __forceinline__ uint32_t block_of(uint32_t jb, uint32_t sh, uint32_t nslog2)
     {
-        heads = h;
+        return (jb << nslog2) + ((sh + jb) & ((1u << nslog2) - 1u));
+    }
+    /* home shard: the wave's XCD, and -- with 64 shards -- one of that XCD's eight by workgroup */
+    static __device__ __forceinline__ uint32_t home_of(uint32_t nshards)
+    {
+        return (xcc_id() | ((blockIdx.x >> 3) << 3)) & (nshards - 1u);
+    }
+    __device__ __forceinline__ void init(uint32_t* h, uint32_t groups, uint32_t group_items, uint32_t shift,
+                                         uint32_t rmin, uint32_t rmax, uint32_t ln, uint32_t nslog2)
+    {
+        heads = h; ns_log2 = nslog2; ns = 1u << nslog2;
         n_groups = groups; group = group_items; len_words = nullptr; len_cap = 0;
         run_shift = shift; run_min = rmin; run_max = rmax; run_even = 0u; lane = ln;
-        shard = xcc_id(); tried = 0; seen = 0; max_tries = (uint32_t)kShards;
+        shard = home_of(ns); tried = 0; seen = 0; max_tries = ns;
         cur_n = cur_raw = 0;
     }
     __device__ __forceinline__ void init_lengths(uint32_t* h, const uint32_t* lengths, uint32_t cap, uint32_t shift,
-                                                 uint32_t rmin, uint32_t rmax, uint32_t ln)
+                                                 uint32_t rmin, uint32_t rmax, uint32_t ln, uint32_t nslog2)
     {
-        init(h, 0, 1, shift, rmin, rmax, ln);
+        init(h, 0, 1, shift, rmin, rmax, ln, nslog2);
         len_words = lengths; len_cap = cap;
     }
     /* Probing every other shard before exiting costs up to 8 dependent atomics per wave, and all waves of
@@ -573,12 +598,22 @@ struct WaveQueue {
     __device__ __forceinline__ void set_probes(uint32_t flags)
     {
         const uint32_t p = (flags >> kQueueProbeShift) & 0xFu;
-        if (p == 0u || p >= (uint32_t)kShards) return;
+        if (p == 0u || p >= ns) return;
         max_tries = p;
         /* with limited probing every shard must be SOMEBODY's home whatever the hardware's workgroup ->
          * XCD placement is: take the home from the workgroup index (identical to the XCD id under the
          * usual round-robin dispatch).  The host only limits probing on grids of >= 64 workgroups. */
-        shard = blockIdx.x & (uint32_t)(kShards - 1);
+        shard = blockIdx.x & (ns - 1u);
+    }
+    /* the next shard to try: with 64 shards the other seven of the same XCD first (s + 8, s + 16, ...) */
+    __device__ __forceinline__ void advance()
+    {
+        if (ns > (uint32_t)kShards) {
+            shard = (shard + (uint32_t)kShards) & (ns - 1u);
+            if ((tried & 7u) == 0u) shard = (shard + 1u) & (ns - 1u);
+        } else {
+            shard = (shard + 1u) & (ns - 1u);
+        }
     }
     /* hands out the next run [begin, begin+count) of shard `sh`; false = no work left anywhere */
     __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& count, uint32_t& sh)
@@ -598,7 +633,7 @@ struct WaveQueue {
         /* shards known to be empty cost no atomic (a follow-up pass may have nothing to do) */
         while (shard_len(shard) == 0u) {
             if (++tried >= max_tries) return false;
-            shard = (shard + 1u) & (uint32_t)(kShards - 1);
+            advance();
             seen = 0;
         }
         cur_n = run_len(shard, seen); cur_raw = claim(shard, cur_n);
@@ -608,7 +643,7 @@ struct WaveQueue {
             if (b >= l) {
                 do {
                     if (++tried >= max_tries) return false;
-                    shard = (shard + 1u) & (uint32_t)(kShards - 1);
+                    advance();
                 } while (shard_len(shard) == 0u);
                 seen = 0;
                 cur_n = run_len(shard, seen);
@@ -652,7 +687,7 @@ struct RingWriter {
 
     __device__ __forceinline__ void init(WaveRing<T, NF>* r, const StreamRef& o, uint32_t ln)
     {
-        ring = r; out = o; lane = ln; head = tail = 0; home = xcc_id();
+        ring = r; out = o; lane = ln; head = tail = 0; home = WaveQueue::home_of(o.nregions);
     }
     /* one block of the home region (one atomicAdd on the region's counter: 8 counters share the
      * load); a full region spills to the next one -- the 8 regions together hold 1.5x the worst case */
@@ -662,13 +697,13 @@ struct RingWriter {
         const uint64_t st0 = __builtin_amdgcn_s_memtime();
         struct Acc { uint64_t& a; uint64_t t0; __device__ ~Acc() { a += __builtin_amdgcn_s_memtime() - t0; } } acc_{st_block, st0};
 #endif
-        for (uint32_t t = 0; t < (uint32_t)kShards; ++t) {
-            region = (home + t) & (uint32_t)(kShards - 1);
+        for (uint32_t t = 0; t < out.nregions; ++t) {
+            region = (home + t) & (out.nregions - 1u);
             uint32_t v = 0;
             if (lane == 0) v = atomicAdd(&out.n_blocks[region * kShardStrideWords], 1u);
             blk = __builtin_amdgcn_readfirstlane(v);
             if (blk < out.region_blocks) {
-                if (out.rotate) home = (region + 1u) & (uint32_t)(kShards - 1);
+                if (out.rotate) home = (region + 1u) & (out.nregions - 1u);
                 return true;
             }
         }
@@ -1055,7 +1090,7 @@ tile_kernel(const LaunchArgs A)
     writer.init(&rings[EFFECTS ? 0 : (threadIdx.x >> 6)], A.out, (uint32_t)lane);
 
     WaveQueue q;
-    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, (uint32_t)lane);
+    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, (uint32_t)lane, A.q.ns_log2);
     q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
@@ -1073,7 +1108,7 @@ tile_kernel(const LaunchArgs A)
         diag_items += count;
         for (uint32_t j = begin; j < begin + count; ++j) {
             /* shard-local index -> sub-tile id: blocks of kShardBlock sub-tiles dealt round-robin to the shards */
-            const uint32_t blk = (j / kShardBlock) * kShards + cur_shard;
+            const uint32_t blk = WaveQueue::block_of(j / kShardBlock, cur_shard, A.q.ns_log2);
             if (blk >= A.q.n_blk) continue;
             const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
             if (sid >= A.q.n_items) continue;
@@ -1454,18 +1489,18 @@ struct LeanQueue {
     __device__ __forceinline__ void init()
     {
         KArgs K = kargs();
-        const uint32_t p = (K->q.flags >> kQueueProbeShift) & 0xFu;
-        shard = (p == 0u || p >= (uint32_t)kShards) ? xcc_id() : (blockIdx.x & (uint32_t)(kShards - 1));
+        const uint32_t p = (K->q.flags >> kQueueProbeShift) & 0xFu, nsh = 1u << K->q.ns_log2;
+        shard = (p == 0u || p >= nsh) ? WaveQueue::home_of(nsh) : (blockIdx.x & (nsh - 1u));
         tried = 0; seen = 0;
     }
     __device__ __forceinline__ bool next(uint32_t lane, uint32_t& begin, uint32_t& count, uint32_t& sh, uint32_t even = 0u)
     {
         KArgs K = kargs();
         WaveQueue q;
-        q.init(K->q.heads, K->q.n_blk, (uint32_t)kShardBlock, K->q.run_shift, K->q.run_min, K->q.run_max, lane);
+        q.init(K->q.heads, K->q.n_blk, (uint32_t)kShardBlock, K->q.run_shift, K->q.run_min, K->q.run_max, lane, K->q.ns_log2);
         q.run_even = even;
         const uint32_t p = (K->q.flags >> kQueueProbeShift) & 0xFu;
-        if (p != 0u && p < (uint32_t)kShards) q.max_tries = p;
+        if (p != 0u && p < q.ns) q.max_tries = p;
         q.shard = shard; q.tried = tried; q.seen = seen;
         const bool got = q.next(begin, count, sh);
         shard = q.shard; tried = q.tried; seen = q.seen;
@@ -1480,14 +1515,14 @@ struct LeanWriter {
 #ifdef FR_STAMP
     uint64_t st_block = 0;
 #endif
-    __device__ __forceinline__ void init() { head = tail = 0; home = xcc_id(); }
+    __device__ __forceinline__ void init() { head = tail = 0; home = WaveQueue::home_of(kargs()->out.nregions ? kargs()->out.nregions : (uint32_t)kShards); }
     __device__ __forceinline__ void write_block(WaveRing<T, NF>* ring, uint32_t lane, uint32_t nvalid)
     {
         KArgs K = kargs();
         RingWriter<T, NF> w;
         w.ring = ring; w.lane = lane;
         w.out.base = K->out.base; w.out.n_blocks = K->out.n_blocks; w.out.region_blocks = K->out.region_blocks;
-        w.out.rotate = K->out.rotate; w.out.overflow = K->out.overflow; w.head = head; w.tail = tail; w.home = home;
+        w.out.rotate = K->out.rotate; w.out.overflow = K->out.overflow; w.out.nregions = K->out.nregions; w.head = head; w.tail = tail; w.home = home;
         w.write_block(nvalid);
         head = w.head; home = w.home;
 #ifdef FR_STAMP
@@ -1583,7 +1618,7 @@ tile_lean_kernel(const LaunchArgs A)
             uint32_t n, sid, stx, sty;
             {
                 KArgs K = kargs();
-                const uint32_t blk = (j / kShardBlock) * kShards + cur_shard;
+                const uint32_t blk = WaveQueue::block_of(j / kShardBlock, cur_shard, K->q.ns_log2);
                 if (blk >= K->q.n_blk) break;
                 uint32_t jb = (j | (uint32_t)(kShardBlock - 1)) + 1u;
                 jb = jb < jend ? jb : jend;
@@ -1722,7 +1757,7 @@ stream_kernel(const LaunchArgs A)
 
     /* region k of the input stream is shard k of the queue; its length was written by the previous launch */
     WaveQueue q;
-    q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
+    q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max, lane, A.q.ns_log2);
     q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
@@ -1891,9 +1926,9 @@ pool_kernel(const LaunchArgs A)
 
     WaveQueue q;
     if constexpr (FROM_STREAM)
-        q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
+        q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max, lane, A.q.ns_log2);
     else
-        q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
+        q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane, A.q.ns_log2);
     q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
@@ -2008,7 +2043,7 @@ pool_kernel(const LaunchArgs A)
                         }
                     } else {
                         /* pixel l of sub-tile j (shard-local index) */
-                        const uint32_t blk = (j / kShardBlock) * kShards + res_shard;
+                        const uint32_t blk = WaveQueue::block_of(j / kShardBlock, res_shard, A.q.ns_log2);
                         const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
                         const uint32_t sty = A.q.nsx_shift >= 0 ? sid >> A.q.nsx_shift : sid / A.q.nsx;
                         const uint32_t stx = sid - sty * A.q.nsx;
@@ -2382,7 +2417,7 @@ fused_kernel(const LaunchArgs A)
     uint32_t rhead = 0, rtail = 0;                           /* wave-uniform record counters */
 
     WaveQueue q;
-    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
+    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane, A.q.ns_log2);
     q.set_probes(A.q.flags);
 
     uint64_t diag_t0 = 0;
@@ -2441,7 +2476,7 @@ fused_kernel(const LaunchArgs A)
                 diag_items += count;
             }
             const uint32_t j = res_next++;
-            const uint32_t blk = (j / kShardBlock) * kShards + res_shard;
+            const uint32_t blk = WaveQueue::block_of(j / kShardBlock, res_shard, A.q.ns_log2);
             if (blk >= A.q.n_blk) continue;
             const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
             if (sid >= A.q.n_items) continue;
@@ -2766,11 +2801,11 @@ deep_zoom_kernel(const DeepZoomArgs A)
     const int n_ref = max_iter < ref_iter ? max_iter : ref_iter;
 
     WaveQueue q;
-    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane);
+    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane, A.q.ns_log2);
     uint32_t begin, count, cur_shard;
     while (q.next(begin, count, cur_shard)) {
         for (uint32_t j = begin; j < begin + count; ++j) {
-            const uint32_t blk = (j / kShardBlock) * kShards + cur_shard;
+            const uint32_t blk = WaveQueue::block_of(j / kShardBlock, cur_shard, A.q.ns_log2);
             if (blk >= A.q.n_blk) continue;
             const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
             if (sid >= A.q.n_items) continue;

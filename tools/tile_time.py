@@ -12,6 +12,13 @@ import fractalrenderer_amd as fr
 from bench import WORKLOADS
 args = sys.argv[1:]
 rounds = int(args.pop(0)) if args and args[0].isdigit() else 15
+# the first renders of a process run on a cold chip (clocks, power state: the first workload listed measured up to 10 %
+# slower than the same one listed later): warm it up
+_w = WORKLOADS["c2"]; _r = fr.Renderer(0)
+_o = torch.empty((_w["H"], _w["W"], 4), dtype=torch.float32, device="cuda:0")
+for _ in range(300):
+    _r.render(fr.FractalState(**_w["state"]), _w["W"], _w["H"], fractal_type=fr.FractalType[_w["fractal"]], precision=fr.Precision[_w["precision"]], rgba=_o)
+torch.cuda.synchronize(); del _o, _r
 for name in args or ["c2", "c3"]:
     opts = []; plane = "rgba"
     if ":" in name:
