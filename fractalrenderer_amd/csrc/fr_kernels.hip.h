@@ -1188,12 +1188,12 @@ tile_kernel(const LaunchArgs A)
                             if (A.interior_style == 1) { coloured = true; }
                             else if (A.interior_style == 2) {
                                 const float tf = expf(-(float)min_trap * 6.0f / fmaxf(S.trap_radius, 1e-6f));
-                                palette_eval(A.pal, S.pal, S.color_offset + tf * 0.3f, rgb);
+                                palette_eval(kargs()->pal, S.pal, S.color_offset + tf * 0.3f, rgb);
                                 coloured = true;
                             }
                         }
                         if (!coloured) {
-                            palette_eval(A.pal, S.pal, pal_arg(t + (T)S.color_offset), rgb);
+                            palette_eval(kargs()->pal, S.pal, pal_arg(t + (T)S.color_offset), rgb);
                             if (A.trap_enabled) {                             /* :193-198 */
                                 const float r = fmaxf(S.trap_radius, 1e-6f);
                                 const float tf = expf(-(float)min_trap * 4.0f / r);
@@ -1242,7 +1242,7 @@ tile_kernel(const LaunchArgs A)
                             if (A.trap_enabled && want_rgb) {                 /* burning_ship.comp:302-306 */
                                 const float infl = 1.0f - clamp01((float)min_dist * 2.0f);
                                 float tc[3];
-                                palette_eval(A.pal, S.pal, infl, tc);
+                                palette_eval(kargs()->pal, S.pal, infl, tc);
                                 const float k = infl * 0.3f;
                                 for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] * (1.0f - k) + tc[c] * k;
                             }
@@ -1257,7 +1257,7 @@ tile_kernel(const LaunchArgs A)
                                 t = clamp01((float)Real<T>::sqrt(zx * zx + zy * zy) * 0.5f); gain = 0.4f;
                             }
                             if (gain != 0.0f && want_rgb) {
-                                palette_eval(A.pal, S.pal, t, rgb);
+                                palette_eval(kargs()->pal, S.pal, t, rgb);
                                 rgb[0] *= gain; rgb[1] *= gain; rgb[2] *= gain;
                             }
                         }
@@ -1493,11 +1493,16 @@ struct LeanQueue {
         shard = (p == 0u || p >= nsh) ? WaveQueue::home_of(nsh) : (blockIdx.x & (nsh - 1u));
         tried = 0; seen = 0;
     }
+    /* STREAM: the shards are the regions of the input stream (lengths written by the previous launch) */
+    template <bool STREAM = false>
     __device__ __forceinline__ bool next(uint32_t lane, uint32_t& begin, uint32_t& count, uint32_t& sh, uint32_t even = 0u)
     {
         KArgs K = kargs();
         WaveQueue q;
-        q.init(K->q.heads, K->q.n_blk, (uint32_t)kShardBlock, K->q.run_shift, K->q.run_min, K->q.run_max, lane, K->q.ns_log2);
+        if constexpr (STREAM)
+            q.init_lengths(K->q.heads, K->in.n_blocks, K->in.region_blocks, K->q.run_shift, K->q.run_min, K->q.run_max, lane, K->q.ns_log2);
+        else
+            q.init(K->q.heads, K->q.n_blk, (uint32_t)kShardBlock, K->q.run_shift, K->q.run_min, K->q.run_max, lane, K->q.ns_log2);
         q.run_even = even;
         const uint32_t p = (K->q.flags >> kQueueProbeShift) & 0xFu;
         if (p != 0u && p < q.ns) q.max_tries = p;
@@ -1924,12 +1929,10 @@ pool_kernel(const LaunchArgs A)
     const uint32_t refill_at = A.pool_refill_at;
     (void)inv_w; (void)aspect; (void)H; (void)W; (void)center_x; (void)center_y; (void)zoom; (void)resx; (void)resy; (void)inv_h;
 
-    WaveQueue q;
-    if constexpr (FROM_STREAM)
-        q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max, lane, A.q.ns_log2);
-    else
-        q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane, A.q.ns_log2);
-    q.set_probes(A.q.flags);
+    /* queue parameters, stream description and output planes are re-read from the kernel arguments where they are used
+     * (kargs()): held in SGPRs across the iteration loops they were what the PERIOD variant spilled (23 SGPRs) */
+    LeanQueue q;
+    q.init();
 
     uint64_t diag_t0 = 0;
     uint32_t diag_items = 0, diag_claims = 0, diag_dry = 0;
@@ -1983,11 +1986,12 @@ pool_kernel(const LaunchArgs A)
                 T nu;
                 float rgb[3];
                 shade<T, FRACTAL>(*kargs(), S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
-                if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
+                KArgs K = kargs();
+                if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
-                if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
-                if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = nu;
-                if (A.iter) A.iter[pixel] = esc_i;
+                if (K->rgba) K->rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+                if (K->nu) reinterpret_cast<T*>(K->nu)[pixel] = nu;
+                if (K->iter) K->iter[pixel] = esc_i;
                 pixel = kInvalidPixel;
                 fin = 0u;
             }
@@ -2001,11 +2005,11 @@ pool_kernel(const LaunchArgs A)
             if (res_next == res_count * 64u) {
 #ifdef FR_STAMP
                 const uint64_t stq = __builtin_amdgcn_s_memtime();
-                const bool got_q = q.next(res_begin, res_count, res_shard);
+                const bool got_q = q.next<FROM_STREAM>(lane, res_begin, res_count, res_shard);
                 st_acc[0] += __builtin_amdgcn_s_memtime() - stq;
                 if (!got_q) {
 #else
-                if (!q.next(res_begin, res_count, res_shard)) {
+                if (!q.next<FROM_STREAM>(lane, res_begin, res_count, res_shard)) {
 #endif
                     dry = true;
                     /* diagnostics: when this wave found the queue dry, in 100 MHz ticks since its start (bits 32..) */
@@ -2026,7 +2030,8 @@ pool_kernel(const LaunchArgs A)
                     const uint32_t j = res_begin + (t >> 6), l = t & 63u;
                     if constexpr (FROM_STREAM) {
                         /* record l of block j of region res_shard */
-                        const uint8_t* b = A.in.base + ((size_t)res_shard * A.in.region_blocks + j) * kBlockBytes;
+                        KArgs K = kargs();
+                        const uint8_t* b = K->in.base + ((size_t)res_shard * K->in.region_blocks + j) * kBlockBytes;
                         const T* fields = reinterpret_cast<const T*>(b + RingWriter<T, NF>::kHeaderBytes);
                         const uint32_t pix = reinterpret_cast<const uint32_t*>(b)[l];
                         if (pix != kInvalidPixel) {

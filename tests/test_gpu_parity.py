@@ -327,7 +327,7 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
     base = gpu_render(fr, renderer, p, 200, 120)
     assert renderer.last_stages() == 2                     # default: tile pass + lane-pool pass
     opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "stream_workgroups_per_cu", "pool_refill_at",
-            "probes", "stream_probes", "stream_rotate")
+            "probes", "stream_probes", "stream_rotate", "tile_kernel", "tile_pixels", "shards", "regions")
     try:
         for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
             renderer.set_tuning(wg, run, shape)
@@ -343,7 +343,13 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
 
                    dict(staging=2, stage_first=16, stage_ratio=2, stream_workgroups_per_cu=2),
                    dict(staging=3), dict(staging=3, stage_first=64, pool_refill_at=8), dict(staging=3, stage_first=16, pool_refill_at=64),
-                   dict(staging=3, stream_run_max=1, stream_workgroups_per_cu=1), dict(staging=3, pool_refill_at=1)):
+                   dict(staging=3, stream_run_max=1, stream_workgroups_per_cu=1), dict(staging=3, pool_refill_at=1),
+                   # the general tile kernel against the lean one (the default), one and two sub-tiles per trip, 8 and 64
+                   # queue shards / stream regions
+                   dict(tile_kernel=1), dict(tile_pixels=1), dict(tile_pixels=2, staging=1), dict(tile_pixels=1, staging=1),
+                   dict(shards=64), dict(shards=64, regions=8), dict(shards=8, regions=64), dict(shards=64, staging=1),
+                   dict(shards=64, staging=2), dict(shards=64, tile_kernel=1), dict(shards=64, staging=4),
+                   dict(shards=64, probes=1, stream_probes=1), dict(shards=64, tile_pixels=1, stream_rotate=1)):
             for k, v in kw.items():
                 renderer.set_option(k, v)
             cur = gpu_render(fr, renderer, p, 200, 120)
@@ -354,6 +360,49 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
                 renderer.set_option(k, 0)
     finally:
         renderer.set_tuning()
+        for k in opts:
+            renderer.set_option(k, 0)
+
+
+@pytest.mark.parametrize("name", ["seahorse_0008_f64", "c3_julia_f32_centre0", "ship_f64_ragged_mi2048", "julia_c_outside_bailout"])
+def test_lean_tile_kernel_equals_the_general_one(fr, renderer, oracle, name):
+    """tile_lean_kernel (coordinate tables, NaN-threshold parking, two sub-tiles per trip) against tile_kernel, and 64
+    queue shards / stream regions against 8: byte-identical planes on ragged sizes (odd numbers of sub-tiles per row:
+    trips whose second sub-tile does not exist), one-pass and staged, whole frames and row-strip shards whose strips are
+    whole sub-tile rows (the lean kernel's condition; other strip heights take the general kernel)."""
+    p, _, _ = CASES[name]
+    opts = ("tile_kernel", "tile_pixels", "shards", "regions", "staging", "periodicity")
+    try:
+        for W, H in ((200, 120), (9, 9), (136, 8), (17, 64), (1, 1), (264, 40)):
+            for staging in (0, 1):
+                renderer.set_option("staging", staging)
+                renderer.set_option("tile_kernel", 1)
+                renderer.set_option("shards", 8)
+                base = gpu_render(fr, renderer, p, W, H)
+                for kw in (dict(), dict(tile_pixels=1), dict(shards=64), dict(shards=64, tile_pixels=1), dict(periodicity=-1),
+                           dict(shards=64, regions=8)):
+                    renderer.set_option("tile_kernel", 0)
+                    for k in ("tile_pixels", "shards", "regions", "periodicity"):
+                        renderer.set_option(k, kw.get(k, 0))
+                    cur = gpu_render(fr, renderer, p, W, H)
+                    for a, b in zip(base, cur):
+                        assert np.array_equal(a, b), (W, H, staging, kw)
+        # row strips: 8 and 16 rows per strip run the lean kernel, 4 the general one
+        renderer.set_option("staging", 0)
+        for k in ("tile_pixels", "shards", "regions", "periodicity"):
+            renderer.set_option(k, 0)
+        W, H = 200, 120
+        whole = gpu_render(fr, renderer, p, W, H)
+        for nparts, R in ((2, 8), (3, 16), (2, 4)):
+            for part in range(nparts):
+                sh = fr.Shard(part, nparts, R)
+                rows = sh.global_rows(H)
+                for shards in (0, 64):
+                    renderer.set_option("shards", shards)
+                    got = gpu_render(fr, renderer, p, W, H, shard=sh)
+                    for a, b in zip(whole, got):
+                        assert np.array_equal(a[rows], b), (nparts, R, part, shards)
+    finally:
         for k in opts:
             renderer.set_option(k, 0)
 
@@ -563,9 +612,19 @@ def test_c2_full_size_properties(fr, renderer, oracle):
         renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
         assert renderer.last_stages() == 1
         assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba)
+        renderer.set_option("staging", 0)
+        # the general tile kernel / 8 shards and regions / one sub-tile per trip against the defaults (lean, 64, two)
+        for kw in (dict(tile_kernel=1), dict(shards=8), dict(tile_pixels=1), dict(shards=64, regions=8), dict(tile_kernel=1, shards=8)):
+            for k, v in kw.items():
+                renderer.set_option(k, v)
+            renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
+            assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba), kw
+            for k in kw:
+                renderer.set_option(k, 0)
     finally:
         renderer.set_tuning()
-        renderer.set_option("staging", 0)
+        for k in ("staging", "tile_kernel", "shards", "regions", "tile_pixels"):
+            renderer.set_option(k, 0)
     tot_it, tot_nu = 0, 0.0
     for part in range(8):
         sh = fr.Shard(part, 8, 32)
