@@ -1456,20 +1456,21 @@ __device__ __forceinline__ void escape_run_lean(Orbit<T> (&o)[NP], const T B2x4,
         do {
             T r2x4[NP];
             bool e[NP];
-            uint64_t em = 0ull;
+            uint64_t m[NP], em = 0ull;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 orbit_step<T, ABS>(o[p]);
                 r2x4[p] = orbit_r2x4(o[p]);
                 e[p] = r2x4[p] > thr[p];                   /* false for ever once thr is NaN */
-                em |= __builtin_amdgcn_ballot_w64(e[p]);
+                m[p] = __builtin_amdgcn_ballot_w64(e[p]);
+                em |= m[p];
             }
             if (em != 0ull) {
                 all = ~0ull;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     if (e[p]) { esc_i[p] = i; esc_r2x4[p] = r2x4[p]; finish(thr[p]); }
-                    done[p] |= __builtin_amdgcn_ballot_w64(e[p]);
+                    done[p] |= m[p];
                     all &= done[p];
                 }
                 event = true;
