@@ -171,6 +171,7 @@ struct LdsBlock {
     float bailout, color_offset, color_scale, trap_radius, stripe_density;
     float brightness, saturation, contrast;
     int32_t max_iter, W, H, aa;
+    float interior_rgb[3];       /* colour of a sample that never escaped (stage_interior): the same for every such sample */
 };
 
 __device__ __forceinline__ void stage_constants(LdsBlock& S, const LaunchArgs& A)
@@ -458,7 +459,26 @@ __device__ __forceinline__ void shade(ARGS& A, const LdsBlock& S, const LogTab<T
             }
         }
     }
-    if (want_rgb) colour_of<T, FRACTAL>(A, S, nu, it >= max_iter, rgb);
+    if (want_rgb) {
+        /* Samples that never escaped all get one colour (nu = max_iter): computed once per workgroup (stage_interior).
+         * A wave that retires only such samples -- C2's lane pool: 92 % of its records, mostly retiring together when a
+         * deadline or a closed cycle takes a whole refill group -- skips the colour stage altogether. */
+        const bool escaped = it < max_iter;
+        if (__builtin_amdgcn_ballot_w64(escaped) != 0ull) colour_of<T, FRACTAL>(A, S, nu, false, rgb);
+        if (!escaped) { rgb[0] = S.interior_rgb[0]; rgb[1] = S.interior_rgb[1]; rgb[2] = S.interior_rgb[2]; }
+    }
+}
+
+/* the colour of interior samples, by the same colour_of() every sample used to run: thread 0, once per workgroup */
+template <typename T, int FRACTAL>
+__device__ __forceinline__ void stage_interior(LdsBlock& S, const LaunchArgs& A)
+{
+    if (threadIdx.x == 0) {
+        float rgb[3] = {0.0f, 0.0f, 0.0f};
+        colour_of<T, FRACTAL>(A, S, (T)A.max_iter, true, rgb);
+        S.interior_rgb[0] = rgb[0]; S.interior_rgb[1] = rgb[1]; S.interior_rgb[2] = rgb[2];
+    }
+    __syncthreads();
 }
 
 /* ---- recolour from the smooth-count plane ---------------------------------------------------------
@@ -1058,6 +1078,7 @@ tile_kernel(const LaunchArgs A)
     __shared__ LdsBlock S;
     __shared__ WaveRing<T, NF> rings[EFFECTS ? 1 : kWavesPerBlock];
     stage_constants(S, A);
+    stage_interior<T, FRACTAL>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 
@@ -1572,6 +1593,7 @@ tile_lean_kernel(const LaunchArgs A)
     __shared__ LdsBlock S;
     __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
     stage_constants(S, A);
+    stage_interior<T, FRACTAL>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 
@@ -1747,6 +1769,7 @@ stream_kernel(const LaunchArgs A)
     __shared__ LdsBlock S;
     __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
     stage_constants(S, A);
+    stage_interior<T, FRACTAL>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 
@@ -1909,6 +1932,7 @@ pool_kernel(const LaunchArgs A)
 
     __shared__ LdsBlock S;
     stage_constants(S, A);
+    stage_interior<T, FRACTAL>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 
@@ -2398,6 +2422,7 @@ fused_kernel(const LaunchArgs A)
     __shared__ LdsBlock S;
     __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
     stage_constants(S, A);
+    stage_interior<T, FRACTAL>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 

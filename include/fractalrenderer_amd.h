@@ -189,10 +189,11 @@ int fr_render_shard(fr_ctx* ctx, const fr_params* p, uint32_t width, uint32_t he
 
 /* Asynchronous form for frame pipelining: enqueues on `hip_stream` (a hipStream_t passed
  * as void*; NULL = the context's own stream) and returns without waiting.  Device memory only.
- * STEADY STATE it is launch-only (one memset node + the kernel launches + two event records: no
- * allocation, no host synchronisation, capturable into a hipGraph).  What is not steady state:
+ * STEADY STATE it is launch-only (kernel launches -- a small one that clears the control block and writes the frame's
+ * coordinate tables, then the render's -- + two event records: no allocation, no host synchronisation, capturable
+ * into a hipGraph).  What is not steady state:
  *   - the first render of a geometry LARGER than any before it on this context grows the context's
- *     survivor-stream scratch (hipFree + hipMalloc), and the first render of a new (W, H, fractal,
+ *     survivor-stream scratch and coordinate tables (hipFree + hipMalloc), and the first render of a new (W, H, fractal,
  *     precision) checks on the host that the divide-free viewport map is exact for every column and row
  *     (a loop over W + H numerators, cached for 8 geometries).  fr_ctx_reserve() does both ahead of time;
  *   - Deep_Zoom with use_perturbation recomputes the fp64 reference orbit on the host for every frame, as
@@ -239,10 +240,18 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue may claim in a stream pass
  *   "stream_workgroups_per_cu"          workgroups per compute unit of the stream pass
  *   "probes", "stream_probes"  queue shards a wave tries before it exits, tile pass / stream passes
- *                        (1..8; 0 = automatic: 1 for a staged or short-orbit tile pass, 4 for stream passes,
- *                        all 8 otherwise and on grids of fewer than 64 workgroups)
- *   "stream_rotate"      2 = survivor-stream writers rotate over the 8 regions (equal regions), 1 = one region
+ *                        (1..15; 0 = automatic: 1 (2 with 64 shards) for a staged or short-orbit tile pass, 4 for stream
+ *                        passes, all shards otherwise and on grids of fewer workgroups than shards)
+ *   "shards", "regions"  8 or 64: shards of the work queue / regions of the survivor streams (each has ONE head word that
+ *                        its waves update with returning atomics, ~15 ns apart).  0 = automatic: 64 (8 per XCD) for
+ *                        launches whose waves stop at their home shards on grids of >= 512 workgroups, else 8; regions
+ *                        follow the shards
+ *   "stream_rotate"      2 = survivor-stream writers rotate over the regions (equal regions), 1 = one region
  *                        per XCD, 0 = automatic (= 2)
+ *   "tile_kernel"        1 = the general tile kernel; 0 = automatic: the LEAN tile kernel (coordinate tables written by a
+ *                        small launch in front of the render, two 8x8 sub-tiles per wave and trip) for every one-sample
+ *                        render without effects on 8x8 sub-tiles whose row strips, if sharded, are whole sub-tile rows.
+ *                        "tile_pixels" = 1 / 2 sub-tiles per trip of the lean kernel (0 = 2)
  *   "periodicity"        -1 = off, 0 = automatic (ON), 1 = on, N > 1 = on with a first snapshot window of N iterations.
  *                        Cycle closing: the kernels keep, per lane, the orbit state at the wave's last snapshot; a lane whose
  *                        state returns to it is on a cycle, can never escape, and is retired as interior at once instead
@@ -252,7 +261,7 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                        iterations executed -- the reference's shaders iterate every interior sample to max_iter (C2:
  *                        1.4x fewer, a filled Julia set 2.8x; views without attracting cycles pay ~2 % for the compares).
  *                        Takes effect in the lane-pool pass and the fused launch, and where the tile kernel itself runs
- *                        samples to max_iter with 8x8 sub-tiles (one-pass frames, SSAA); not in the effects variants, the
+ *                        samples to max_iter (one-pass frames on 8x8 sub-tiles, SSAA); not in the effects variants, the
  *                        block-stage schedule, the fresh-pixel pool or Deep_Zoom.  bench.py's headline switches it OFF so
  *                        that its roofline is quoted on the reference's iteration count.
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1
