@@ -14,7 +14,8 @@ rng = np.random.default_rng(seed)
 r = fr.Renderer(0)
 anchors = {0: [(-0.743643887037151, 0.13182590420533), (-0.1011, 0.9563), (-1.25066, 0.02012), (0.275, 0.0), (-0.5, 0.0), (-1.7497, 0.00001)],
            1: [(0.0, 0.0), (0.3, 0.2), (-0.6, 0.1)], 2: [(-1.755, -0.03), (-0.5, -0.5), (-1.62, -0.002)]}
-opts = ["staging", "pool_refill_at", "probes", "stream_probes", "stream_rotate", "stage_first", "subtile_shape", "workgroups_per_cu", "periodicity"]
+opts = ["staging", "pool_refill_at", "probes", "stream_probes", "stream_rotate", "stage_first", "subtile_shape", "workgroups_per_cu", "periodicity",
+        "tile_kernel", "tile_pixels", "shards", "regions"]
 bad = 0
 for trial in range(trials):
     fractal = int(rng.integers(0, 3)); prec = int(rng.integers(0, 2))
@@ -44,10 +45,14 @@ for trial in range(trials):
                 "probes": int(rng.choice([0, 1, 2, 8])), "stream_probes": int(rng.choice([0, 1, 4, 8])), "stream_rotate": int(rng.choice([0, 1, 2])),
                 "stage_first": int(rng.choice([0, 16, 48, 160])), "subtile_shape": int(rng.choice([0, 3, 4, 6])), "workgroups_per_cu": int(rng.choice([0, 1, 3, 7]))}
     tune["periodicity"] = int(rng.choice([-1, 0, 1, 16, 64, 1000]))            # exact cycle closing: never changes a pixel
+    # lean / general tile kernel, one or two sub-tiles per trip, 8 or 64 queue shards and stream regions
+    tune.update(tile_kernel=int(rng.choice([0, 0, 1])), tile_pixels=int(rng.choice([0, 1, 2])), shards=int(rng.choice([0, 8, 64])),
+                regions=int(rng.choice([0, 0, 8, 64])))
     for k in opts: r.set_option(k, tune.get(k, 0))
     shard = None
     if trial % 3 == 1:
-        n = int(rng.integers(2, 9)); shard = fr.Shard(int(rng.integers(0, n)), n, int(rng.integers(1, 40)))
+        n = int(rng.integers(2, 9))
+        shard = fr.Shard(int(rng.integers(0, n)), n, int(rng.choice([8, 16, 24, 32])) if rng.random() < 0.5 else int(rng.integers(1, 40)))
     if shard is not None and shard.rows(H) == 0:
         continue
     try:
