@@ -2447,9 +2447,8 @@ fused_kernel(const LaunchArgs A)
     WaveRing<T, NF>* ring = &rings[threadIdx.x >> 6];
     uint32_t rhead = 0, rtail = 0;                           /* wave-uniform record counters */
 
-    WaveQueue q;
-    q.init(A.q.heads, A.q.n_blk, (uint32_t)kShardBlock, A.q.run_shift, A.q.run_min, A.q.run_max, lane, A.q.ns_log2);
-    q.set_probes(A.q.flags);
+    LeanQueue q;                 /* queue parameters and output planes re-read from the kernel arguments (kargs()) */
+    q.init();
 
     uint64_t diag_t0 = 0;
     uint32_t diag_items = 0, diag_claims = 0, diag_dry = 0;
@@ -2481,11 +2480,12 @@ fused_kernel(const LaunchArgs A)
                 T nu;
                 float rgb[3];
                 shade<T, FRACTAL>(*kargs(), S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
-                if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
+                KArgs K = kargs();
+                if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
-                if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
-                if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = nu;
-                if (A.iter) A.iter[pixel] = esc_i;
+                if (K->rgba) K->rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+                if (K->nu) reinterpret_cast<T*>(K->nu)[pixel] = nu;
+                if (K->iter) K->iter[pixel] = esc_i;
                 pixel = kInvalidPixel;
                 fin = 0u;
             }
@@ -2497,7 +2497,7 @@ fused_kernel(const LaunchArgs A)
         while (!dry && rtail - rhead < nfree) {
             if (res_next == res_end) {
                 uint32_t begin, count;
-                if (!q.next(begin, count, res_shard)) {
+                if (!q.next(lane, begin, count, res_shard)) {
                     dry = true;
                     diag_dry = A.diag ? (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0) : 0u;
                     break;
@@ -2587,11 +2587,12 @@ fused_kernel(const LaunchArgs A)
                 T nu;
                 float rgb[3];
                 shade<T, FRACTAL>(*kargs(), S, lg, it, r2, want_nu, want_rgb, nu, rgb);
-                if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
+                KArgs K = kargs();
+                if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
                     post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
-                if (A.rgba) A.rgba[tpixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
-                if (A.nu) reinterpret_cast<T*>(A.nu)[tpixel] = nu;
-                if (A.iter) A.iter[tpixel] = it;
+                if (K->rgba) K->rgba[tpixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+                if (K->nu) reinterpret_cast<T*>(K->nu)[tpixel] = nu;
+                if (K->iter) K->iter[tpixel] = it;
             }
         }
 
