@@ -404,8 +404,8 @@ static uint32_t ceil_log2(uint32_t v)
 }
 
 /* control block in device memory, zeroed by ONE memset per render:
- *   words [s * 256, s * 256 + 256): the 8 queue heads of stage s (128 B apart)
- *   words [(kMaxStages + s) * 256, +256): the 8 region counters of the survivor stream written by stage s */
+ *   words [s * kStageWords, + kMaxShards * 32): the (8 or 64) queue heads of stage s, 128 B apart
+ *   the next kMaxShards * 32 words: the (8 or 64) region counters of the survivor stream written by stage s */
 static uint32_t* stage_heads(fr_ctx* c, int s) { return c->d_ctrl + (size_t)s * kStageWords; }
 static uint32_t* stage_counter(fr_ctx* c, int s) { return c->d_ctrl + (size_t)s * kStageWords + (size_t)kMaxShards * kShardStrideWords; }
 
@@ -558,9 +558,9 @@ static bool needs_effects(const fr_params* p)
 }
 
 /* ---- geometry of the tile pass ----------------------------------------------------------------------
- * Sub-tiles of 64 pixels (2^shape wide) in blocks of 16 dealt round-robin to the 8 shards over a
- * power-of-two padded block index space (optionally bit-reversed; blocks >= n_blk are skipped by the
- * kernel); a persistent grid of exactly the resident set; run lengths and probe limit of the queue. */
+ * Sub-tiles of 64 pixels (2^shape wide) in blocks of 16 dealt round by round to the 8 or 64 shards, a shard's place
+ * rotating with the round (WaveQueue::block_of; blocks >= n_blk are skipped by the kernels); a persistent grid of
+ * exactly the resident set; run lengths and probe limit of the queue. */
 static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_local, int shape, bool bounded, bool moderate,
                                  uint32_t* grid_out, uint32_t* waves_per_shard_out)
 {
@@ -674,7 +674,7 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t
 }
 
 /* Survivor streams: blocks of 64 records {pixel u32, iterations done u32, nfields x T}.  Worst case: every
- * sample survives (npx/64 full blocks) + one partial block per writer wave; the 8 regions of a stream hold
+ * sample survives (npx/64 full blocks) + one partial block per writer wave; the regions of a stream hold
  * 1.5x that, so a region that fills up can spill into its neighbours.  Grow-only (happens on the first
  * render of a larger geometry, not capturable).  The default schedule (tile pass + one pool pass) writes
  * one stream; the second buffer only exists for schedules with three or more passes (4 GB less scratch
@@ -756,7 +756,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     int bounds[kMaxStages];
     const int nstage = plan_stages(c, p, effects, (size_t)rows_local * W, bounds);
     const bool staged = nstage > 1;
-    /* survivor-stream writers move to the next region after every block: the 8 regions come out equally
+    /* survivor-stream writers move to the next region after every block: the regions come out equally
      * long with the same mix of blocks, so the reading pass is balanced with little stealing (measured,
      * profiles/r01_region_rotation.txt: C2 0.883 -> 0.831 ms, C3 0.598 -> 0.539 ms; regions by XCD = 1) */
     const uint32_t rotate_regions = c->tune_stream_rotate == 1u ? 0u : 1u;

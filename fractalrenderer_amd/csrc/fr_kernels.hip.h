@@ -7,24 +7,27 @@
  * (shaders/test_deep_zoom.comp).  How it is computed is MI355X-first and shares nothing with the
  * reference's 16x16-workgroup GLSL dispatch:
  *
- *   - TILE PASS (tile_kernel): one wavefront lane per pixel; a wave owns a "sub-tile" of 64 pixels
- *     (8x8, 16x4 or 64x1 -- every lane row is a whole number of 128-byte lines of the row-major
- *     RGBA-f32 frame, so stores are full-line coalesced).  A PERSISTENT grid pulls runs of sub-tiles
- *     from a queue of 8 shards (heads 128 B apart, home shard = XCD); it runs only the first b0
- *     iterations of every pixel.  Pixels that escaped are shaded and stored; pixels still alive are
- *     COMPACTED -- through a per-wave LDS ring into dense blocks of 64 survivor records {pixel, z, c}
- *     in HBM, the writers rotating over 8 regions.
+ *   - PREPARE (prepare_kernel): a small launch in front of a render: control block zeroed, the frame's W + H
+ *     coordinates (the viewport map is separable) written as two tables.
+ *   - TILE PASS (tile_lean_kernel; tile_kernel is its general form: SSAA, effects, other sub-tile shapes): a wave owns
+ *     "sub-tiles" of 64 pixels (8x8; the general kernel also 16x4 or 64x1 -- every lane row is a whole number of
+ *     128-byte lines of the row-major RGBA-f32 frame, so stores are full-line coalesced), the lean kernel two of them
+ *     per trip (two pixels per lane).  A PERSISTENT grid pulls runs of sub-tiles from a queue of 8 or 64 shards (heads
+ *     128 B apart, home shard by XCD); it runs only the first b0 iterations of every pixel.  Pixels that escaped are
+ *     shaded and stored; pixels still alive are COMPACTED -- through a per-wave LDS ring into dense blocks of 64
+ *     survivor records {pixel, z, c} in HBM, the writers rotating over 8 or 64 regions.
  *   - LANE POOL (pool_kernel): the survivors, to max_iter.  Persistent LANES: a lane that finishes is
  *     refilled with the next record, so waves stay full whatever the spread of escape times and the
  *     frame balances at pixel granularity.  Sub-tile cost varies 100x (a few iterations outside the
  *     set, max_iter inside) and a 64-pixel wave runs as long as its slowest lane (25 % lane occupancy
  *     on a Julia dust): after the tile pass every work item has bounded cost, and the expensive
  *     remainder runs dense.  (stream_kernel, block stages with x4 budgets, is the first form of the
- *     second pass, kept as an option.)  Optional PERIOD variant ("periodicity" option): a lane whose state
- *     returns to its own snapshot is on a cycle and is retired as interior at once -- exact, the planes stay
- *     byte-identical, but fewer iterations run than the reference executes, so it is off by default.
+ *     second pass, kept as an option.)  PERIOD variant ("periodicity" option, the library's default): a lane whose
+ *     state returns to its own snapshot is on a cycle and is retired as interior at once -- exact, the planes stay
+ *     byte-identical, but fewer iterations run than the reference executes (bench.py's headline switches it off).
  *   - the iteration index is wave-uniform and lives in SGPRs; a lane that escapes records
- *     (i, |z|^2) and is parked at the fixed point z = 0, c = 0, so no per-lane "active" predicate
+ *     (i, |z|^2) and is parked at the fixed point z = 0, c = 0 (lean tile kernel: its escape threshold becomes NaN
+ *     instead), so no per-lane "active" predicate
  *     exists in the loop; a tile wave leaves the loop as soon as the ballot of finished lanes is full
  *     (wave-uniform early-out); where escape is absorbing, waves run UNCHECKED blocks of 16 updates
  *     (6 VALU ops each) with rollback + tested replay on a dirty block;
@@ -34,8 +37,9 @@
  *     as-written a*b+c (file is built with -ffp-contract=off).  Where an fma is written explicitly
  *     it multiplies by an exact power of two, which rounds exactly like the as-written
  *     two-operation form (see "scaled-imaginary form" below);
- *   - the palette knot table and the viewport constants are staged once per workgroup into LDS;
- *     every lane reads them from there (broadcast ds_reads).
+ *   - the palette knot table and the viewport constants are staged once per workgroup into LDS (per-lane lookups);
+ *     what steers control flow is read from the kernel arguments (wave-uniform), and arguments needed rarely are
+ *     re-read where they are used (kargs()) instead of being held -- and spilled -- across the main loops.
  *
  * There is no dense contraction in this path: no MFMA.  The bound is fp64 (fp32) VALU issue; HBM
  * traffic is the write-once 16 B/pixel output plus 24-40 B per survivor record, written and read once.
@@ -64,7 +68,7 @@ constexpr int kMaxShards = 64;           /* the largest: 8 per XCD.  A queue hea
 constexpr int kShardStrideWords = 32;    /* 128 B between heads                            */
 constexpr int kShardBlock = 16;          /* sub-tiles are dealt to shards in blocks of 16  */
 constexpr int kFastBlock = 16;           /* iterations per unchecked block                 */
-constexpr uint32_t kQueueProbeShift = 4; /* bits 4-7: shards a wave may probe before giving up (0 = all 8) */
+constexpr uint32_t kQueueProbeShift = 4; /* bits 4-7: shards a wave may probe before giving up (0 = all of them) */
 constexpr uint32_t kInvalidPixel = 0xFFFFFFFFu;
 constexpr int kRingSlots = 128;          /* survivor ring capacity per wave (records)      */
 
@@ -545,7 +549,7 @@ __device__ __forceinline__ uint32_t xcc_id()
 /* ---- XCD-sharded work queue ------------------------------------------------------------------
  * 8 heads, one per XCD.  A wave claims a run of items from its home shard with one atomicAdd,
  * run length clamp(remaining >> run_shift, run_min, run_max); when a shard is dry it moves to
- * the next one and returns false after `max_tries` shards (all 8 by default) were found dry -- every
+ * the next one and returns false after `max_tries` shards (all of them by default) were found dry -- every
  * wave reaches that.  (Claiming the next run ahead of need was measured equal or slower on every
  * workload -- it commits the wave to one more run -- and is gone: the state it carried cost SGPRs.) */
 struct WaveQueue {
@@ -710,7 +714,7 @@ struct RingWriter {
         ring = r; out = o; lane = ln; head = tail = 0; home = WaveQueue::home_of(o.nregions);
     }
     /* one block of the home region (one atomicAdd on the region's counter: 8 counters share the
-     * load); a full region spills to the next one -- the 8 regions together hold 1.5x the worst case */
+     * load); a full region spills to the next one -- the regions together hold 1.5x the worst case */
     __device__ __forceinline__ bool take_block(uint32_t& region, uint32_t& blk)
     {
 #ifdef FR_STAMP
