@@ -562,7 +562,7 @@ static bool needs_effects(const fr_params* p)
  * rotating with the round (WaveQueue::block_of; blocks >= n_blk are skipped by the kernels); a persistent grid of
  * exactly the resident set; run lengths and probe limit of the queue. */
 static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_local, int shape, bool bounded, bool moderate,
-                                 uint32_t* grid_out, uint32_t* waves_per_shard_out)
+                                 bool six_fit, uint32_t* grid_out, uint32_t* waves_per_shard_out)
 {
     const uint32_t fpw = 1u << shape, fph = 64u >> shape;
     QueueArgs tq;
@@ -579,7 +579,8 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
      * shows workgroups beyond the resident set only start when resident ones exit, and find the queue dry):
      * launch exactly the resident set.  Measured 5 vs 4: C2 +1.9 %, C3 +5.6 %, C5 +1.7 %; 6-8 (the one-sample
      * kernel fits 7 at 69 VGPRs) within 1 %. */
-    const uint32_t wg_per_cu = c->tune_wg_per_cu ? c->tune_wg_per_cu : 5u;
+    /* the staged lean tile kernel in fp32 (52 VGPRs, 8.5 KB of LDS) holds 6: C3 -1.4 % */
+    const uint32_t wg_per_cu = c->tune_wg_per_cu ? c->tune_wg_per_cu : (six_fit ? 6u : 5u);
     uint32_t grid = (uint32_t)c->compute_units * wg_per_cu;
     /* never more waves than the shortest runs can feed: a wave takes at least run_min sub-tiles per dequeue (4 when
      * bounded, 2 otherwise), and waves that find nothing still cost their launch and their exit probes -- at 512^2
@@ -774,7 +775,10 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      * the waves stop at their home shard -- the blocks of 16 sub-tiles dealt round-robin keep the shards level */
     const bool moderate = !staged && !effects && (long long)max_iter * aa1 * aa1 < 768;
     uint32_t grid = 0, waves_per_shard = 0;
-    const QueueArgs tq = plan_tile_queue(c, W, rows_local, shape, bounded, moderate, &grid, &waves_per_shard);
+    /* (fp32 only: the fp64 instantiation's 82 VGPRs leave room for 5 waves per SIMD) */
+    const bool lean_staged = !f64 && staged && !fused && !effects && p->antialiasing_samples <= 1 && shape == 3 && c->tune_tile_kernel != 1u &&
+                             (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
+    const QueueArgs tq = plan_tile_queue(c, W, rows_local, shape, bounded, moderate, lean_staged, &grid, &waves_per_shard);
     auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
     c->last_grid = grid;
 

@@ -525,7 +525,7 @@ def test_hot_kernels_keep_their_register_budget(fr):
         # lean tile kernel, two sub-tiles per trip (the default tile pass): 5 workgroups per CU = 5 waves per SIMD
         "_ZN2fr16tile_lean_kernelIdLi0ELb0ELi2EEEvNS_10LaunchArgsE": (96, 5, 16),  # fp64 Mandelbrot, staged (C2/C4/C5)
         "_ZN2fr16tile_lean_kernelIdLi0ELb1ELi2EEEvNS_10LaunchArgsE": (96, 5, 16),  # one-pass frames (C1), cycle closing
-        "_ZN2fr16tile_lean_kernelIfLi1ELb0ELi2EEEvNS_10LaunchArgsE": (64, 5, 0),   # fp32 Julia (C3)
+        "_ZN2fr16tile_lean_kernelIfLi1ELb0ELi2EEEvNS_10LaunchArgsE": (64, 6, 0),   # fp32 Julia (C3): 6 workgroups per CU
         "_ZN2fr16tile_lean_kernelIdLi0ELb0ELi1EEEvNS_10LaunchArgsE": (64, 5, 16),   # one sub-tile per trip
         # general tile kernel (SSAA, other sub-tile shapes, strips that are not whole sub-tile rows), fused launch
         "_ZN2fr11tile_kernelIdLi0ELi3ELb0ELb0ELb1EEEvNS_10LaunchArgsE": (96, 5, 48),
