@@ -526,7 +526,12 @@ clear_words_kernel(uint32_t* __restrict__ p, const uint32_t n)
 #ifdef FR_STAMP
 #define FR_STAMP_DECL uint64_t st_acc[4] = {0, 0, 0, 0}; uint64_t st_t = 0; (void)st_t;
 #define FR_STAMP_BEGIN() do { st_t = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef FR_STAMP_TESTED   /* -DFR_STAMP -DFR_STAMP_TESTED: the slots count updates instead of cycles -- 0: updates a lane-pool wave ran
+                          * TESTED, 2: updates of its dirty unchecked stretches (FR_CLOCK_GHZ=0.001 tools/stamps.py prints counts) */
+#define FR_STAMP_END(k) do {} while (0)
+#else
 #define FR_STAMP_END(k) do { st_acc[k] += __builtin_amdgcn_s_memtime() - st_t; } while (0)
+#endif
 #define FR_STAMP_WRITE(A, lane) do { if ((A).diag && (lane) == 0) { uint64_t* d_ = (A).diag + (size_t)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 8 + 4; \
         d_[0] = st_acc[0]; d_[1] = st_acc[1]; d_[2] = st_acc[2]; d_[3] = st_acc[3]; } } while (0)
 constexpr int kDiagWords = 8;
@@ -2035,7 +2040,9 @@ pool_kernel(const LaunchArgs A)
 #ifdef FR_STAMP
                 const uint64_t stq = __builtin_amdgcn_s_memtime();
                 const bool got_q = q.next<FROM_STREAM>(lane, res_begin, res_count, res_shard);
+#ifndef FR_STAMP_TESTED
                 st_acc[0] += __builtin_amdgcn_s_memtime() - stq;
+#endif
                 if (!got_q) {
 #else
                 if (!q.next<FROM_STREAM>(lane, res_begin, res_count, res_shard)) {
@@ -2314,6 +2321,9 @@ pool_kernel(const LaunchArgs A)
                     /* dirty stretch: locate the escaped lanes' updates (locate_escapes), keep everybody else's progress */
                     uint32_t ek; T er;
                     locate_escapes<T, Form<FRACTAL>::abs_step>(sX, sYd, sx2, sy2d, o.cx, o.cyd, B2x4, bad, badm, len, ek, er);
+#ifdef FR_STAMP_TESTED
+                    st_acc[2] += len;        /* diagnostic: updates of dirty unchecked stretches */
+#endif
                     if (bad) {
                         /* an escape at or past the lane's deadline is no escape: the sample ran its max_iter updates */
                         const int idx = (int)(wclock + ek - (deadline - (uint32_t)max_iter));
@@ -2365,6 +2375,9 @@ pool_kernel(const LaunchArgs A)
                 }
             } while (k < n);
             wclock += k;
+#ifdef FR_STAMP_TESTED
+            st_acc[0] += k;              /* diagnostic: updates this wave ran TESTED */
+#endif
             clean = escaped ? 0u : clean + k;
             if (wclock == next_deadline) reach_deadline(false);
             if constexpr (PERIOD) {
