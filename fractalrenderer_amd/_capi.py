@@ -129,6 +129,17 @@ SIGNATURES = {
 }
 
 
+# internal (fractalrenderer_amd/csrc/fr_tuning.h): queue / stream tuning for tests, tools and A/B measurements
+INTERNAL_SIGNATURES = {
+    "fr_ctx_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "fr_export8_thresholds": (None, [_P(C.c_float)]),          # fr_internal.h: byte thresholds of the 8-bit export
+}
+PUBLIC_OPTIONS = ("periodicity", "staging", "shards", "tile_kernel", "diag_buffer", "diag_stride")
+TUNING_NAMES = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "stage_first", "pool_refill_at", "stream_run_max",
+                "stream_run_min", "stream_workgroups_per_cu", "probes", "stream_probes", "regions", "stream_rotate",
+                "tile_pixels", "subtile_shape", "debug_region_blocks")
+
+
 class FractalRendererError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"fractalrenderer_amd: status {status}: {message}")
@@ -170,7 +181,7 @@ def lib() -> C.CDLL:
                 "or `make -C fractalrenderer_amd/csrc`. There is no Python/CPU fallback for the render path.")
         _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(INTERNAL_SIGNATURES.items()):
             fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args

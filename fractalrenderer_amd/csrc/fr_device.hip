@@ -16,11 +16,11 @@
 #include <string.h>
 
 #include "fr_kernels.hip.h"
+#include "fr_tuning.h"
 
 using namespace fr;
 
-static constexpr int kMaxStages = 16;
-static constexpr uint32_t kAutoStaging = 3u;   /* "staging" = 0: tile pass + lane-pool pass (4, the fused launch, measured slower on whole frames) */
+static constexpr int kMaxStages = 2;            /* tile pass (+ lane-pool pass) */
 static constexpr size_t kStageWords = (size_t)2 * kMaxShards * kShardStrideWords;   /* one stage: its queue heads, then its stream counters */
 static constexpr size_t kCtrlWords = (size_t)kMaxStages * kStageWords;
 
@@ -36,14 +36,12 @@ struct fr_ctx {
     void* orbit_host;           /* Deep_Zoom: pinned staging (fp64 orbit + its float narrowing) */
     float* orbit_dev;           /* Deep_Zoom: reference orbit as float pairs */
     size_t orbit_cap;           /* capacity in scalars (2 per orbit point) */
-    void* stream_buf[2];        /* ping-pong survivor streams */
-    size_t stream_bytes[2];
-    uint32_t tune_pool;         /* 0 = automatic (currently off), 1 = off, 2 = on: lane-pool kernel */
-    uint32_t tune_pool_refill;  /* idle lanes that trigger a refill (0 = 32) */
+    void* stream_buf;           /* survivor stream (tile pass -> lane pool) */
+    size_t stream_bytes;
+    uint32_t tune_pool_refill;  /* lane pool: idle lanes that trigger a refill (0 = 24) */
     int32_t tune_periodicity;   /* cycle closing: -1 off, 0 automatic (on, first window 128), else the first snapshot window in iterations */
-    uint32_t tune_staging;      /* 0 = automatic (currently off), 1 = off (single pass), 2 = on */
-    uint32_t tune_stage_first;  /* first budget b0 (0 = 32) */
-    uint32_t tune_stage_ratio;  /* budget growth per stage (0 = 4) */
+    uint32_t tune_staging;      /* 0 = automatic, 1 = single pass, 3 = tile pass + lane-pool pass whatever max_iter is */
+    uint32_t tune_stage_first;  /* iteration budget b0 of the tile pass (0 = automatic) */
     uint32_t tune_stream_run_max, tune_stream_run_min, tune_stream_wg_per_cu;
     size_t diag_stride;         /* words between the diag regions of consecutive stages */
     int last_stages;
@@ -61,6 +59,7 @@ struct fr_ctx {
     size_t scratch_bytes;
     uint32_t debug_region_blocks; /* tests only: cap the capacity of a survivor-stream region, to provoke an overflow */
     double2* log2_tab;          /* device copy of the log2 table of the fp64 smooth-count epilogue (log2_tab()) */
+    float* export8_thr;         /* device: 256 x {t[b], t[b + 1]}, the byte thresholds of the 8-bit export (fr_export8_thresholds) */
     void* coord_buf;            /* lean tile pass: W + H coordinates of the frame being rendered (prepare_kernel) */
     size_t coord_bytes;
     uint32_t tune_tile_kernel;  /* 0 = automatic (the lean tile kernel where it applies), 1 = the general tile_kernel */
@@ -102,54 +101,58 @@ extern "C" int fr_ctx_create(int device_ordinal, fr_ctx** out)
     if (!c) return fr_set_error(FR_ERR_NOMEM, "out of host memory");
     c->device = device_ordinal;
     c->compute_units = prop.multiProcessorCount;
+    /* log2 table: bin i of [0.5, 1) has midpoint m_i = 0.5 + (i + 0.5) / 256; entry = {y_i = RN(1 / m_i), -log2(y_i)}.
+     * The logarithm is taken of the ROUNDED reciprocal (in 64-bit long double), so that m = (1 + r) / y_i holds for
+     * the r the kernels compute and the table contributes no error of its own beyond its final rounding. */
+    double tab[2 * kLog2Entries];
+    for (int i = 0; i < kLog2Entries; ++i) {
+        const double m = 0.5 + ((double)i + 0.5) / (2.0 * kLog2Entries);
+        const double y = 1.0 / m;
+        tab[2 * i] = y;
+        tab[2 * i + 1] = (double)(-log2l((long double)y));
+    }
+    /* byte thresholds of the 8-bit export as the pairs the kernel reads: {t[b], t[b + 1]} */
+    float t8[257], pairs[512];
+    fr_export8_thresholds(t8);
+    for (int b = 0; b < 256; ++b) { pairs[2 * b] = t8[b]; pairs[2 * b + 1] = t8[b + 1]; }
     hipError_t e2;
     if ((e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_begin)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_end)) != hipSuccess ||
         (e2 = hipMalloc((void**)&c->d_ctrl, kCtrlWords * sizeof(uint32_t))) != hipSuccess ||
         (e2 = hipHostMalloc((void**)&c->overflow_host, 64, hipHostMallocMapped)) != hipSuccess ||
-        (e2 = hipHostGetDevicePointer((void**)&c->overflow_dev, c->overflow_host, 0)) != hipSuccess) {
-        free(c);
+        (e2 = hipHostGetDevicePointer((void**)&c->overflow_dev, c->overflow_host, 0)) != hipSuccess ||
+        (e2 = hipMalloc((void**)&c->log2_tab, sizeof(tab))) != hipSuccess ||
+        (e2 = hipMemcpy(c->log2_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e2 = hipMalloc((void**)&c->export8_thr, sizeof(pairs))) != hipSuccess ||
+        (e2 = hipMemcpy(c->export8_thr, pairs, sizeof(pairs), hipMemcpyHostToDevice)) != hipSuccess) {
+        fr_ctx_destroy(c);                       /* releases whatever was created */
         return fr_set_error(FR_ERR_HIP, "context setup failed: %s", hipGetErrorString(e2));
     }
     *c->overflow_host = 0u;
-    {   /* log2 table: bin i of [0.5, 1) has midpoint m_i = 0.5 + (i + 0.5) / 256; entry = {y_i = RN(1 / m_i), -log2(y_i)}.
-         * The logarithm is taken of the ROUNDED reciprocal (in 64-bit long double), so that m = (1 + r) / y_i holds for
-         * the r the kernels compute and the table contributes no error of its own beyond its final rounding. */
-        double tab[2 * kLog2Entries];
-        for (int i = 0; i < kLog2Entries; ++i) {
-            const double m = 0.5 + ((double)i + 0.5) / (2.0 * kLog2Entries);
-            const double y = 1.0 / m;
-            tab[2 * i] = y;
-            tab[2 * i + 1] = (double)(-log2l((long double)y));
-        }
-        if ((e2 = hipMalloc((void**)&c->log2_tab, sizeof(tab))) != hipSuccess ||
-            (e2 = hipMemcpy(c->log2_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess) {
-            free(c);
-            return fr_set_error(FR_ERR_HIP, "context setup failed: %s", hipGetErrorString(e2));
-        }
-    }
     *out = c;
     return FR_OK;
 }
 
+/* Also the unwinding path of a failed fr_ctx_create: every member may still be NULL. */
 extern "C" void fr_ctx_destroy(fr_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();                /* renders of this context may have been enqueued on callers' streams */
     if (c->scratch) (void)hipFree(c->scratch);
-    (void)hipFree(c->d_ctrl);
+    if (c->d_ctrl) (void)hipFree(c->d_ctrl);
     if (c->overflow_host) (void)hipHostFree(c->overflow_host);
     if (c->log2_tab) (void)hipFree(c->log2_tab);
+    if (c->export8_thr) (void)hipFree(c->export8_thr);
     if (c->coord_buf) (void)hipFree(c->coord_buf);
-    for (int k = 0; k < 2; ++k) if (c->stream_buf[k]) (void)hipFree(c->stream_buf[k]);
+    if (c->stream_buf) (void)hipFree(c->stream_buf);
     if (c->frame_buf) (void)hipFree(c->frame_buf);
     if (c->orbit_host) (void)hipHostFree(c->orbit_host);
     if (c->orbit_dev) (void)hipFree(c->orbit_dev);
-    (void)hipEventDestroy(c->ev_begin);
-    (void)hipEventDestroy(c->ev_end);
-    (void)hipStreamDestroy(c->stream);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     free(c);
 }
 
@@ -159,8 +162,41 @@ extern "C" int fr_ctx_compute_units(fr_ctx* c)
     return c->compute_units;
 }
 
-/* Tuning / diagnostics knobs by name; value 0 restores the automatic choice. */
+/* Options a caller needs, by name; value 0 restores the automatic choice (include/fractalrenderer_amd.h). */
 extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
+{
+    if (!c || !name) return fr_set_error(FR_ERR_INVALID_ARG, "ctx/name is NULL");
+    if (!strcmp(name, "periodicity")) {
+        if (value < -1 || value > (1 << 20)) return fr_set_error(FR_ERR_INVALID_ARG, "periodicity must be -1 (off), 0 (automatic: on), 1 (on) or a first snapshot window in iterations");
+        c->tune_periodicity = value <= 0 ? (int32_t)value : (value == 1 ? 128 : (int32_t)((value + 15) / 16 * 16));
+    } else if (!strcmp(name, "staging")) {
+        /* 2 (block stream passes) and 4 (fused launch) were measured dead ends and left the library in 1.0: accepted,
+         * they select the automatic schedule */
+        if (value < 0 || value > 4) return fr_set_error(FR_ERR_INVALID_ARG, "staging must be 0 (automatic), 1 (single pass) or 3 (tile pass + lane-pool pass)");
+        c->tune_staging = (value == 2 || value == 4) ? 0u : (uint32_t)value;
+    } else if (!strcmp(name, "shards")) {
+        if (value != 0 && value != 8 && value != 64) return fr_set_error(FR_ERR_INVALID_ARG, "shards must be 0 (automatic), 8 or 64");
+        c->tune_shards = (uint32_t)value;
+    } else if (!strcmp(name, "tile_kernel")) {
+        if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "tile_kernel must be 0 (automatic: lean where it applies) or 1 (general)");
+        c->tune_tile_kernel = (uint32_t)value;
+    } else if (!strcmp(name, "diag_buffer")) {
+        c->diag = (uint64_t*)(uintptr_t)value;        /* device pointer, 4 x u64 per wave of the grid; 0 = off */
+    } else if (!strcmp(name, "diag_stride")) {
+        c->diag_stride = (size_t)value;               /* u64 words between the diag regions of consecutive stages */
+    } else if (!strcmp(name, "pool") || !strcmp(name, "stage_ratio") || !strcmp(name, "pool_evict_at") ||
+               !strcmp(name, "pool_passes") || !strcmp(name, "queue_flags")) {
+        /* retired with the schedules they steered (fresh-pixel pool, block stages, eviction passes): accepted, ignored */
+    } else {
+        return fr_set_error(FR_ERR_INVALID_ARG, "unknown option '%s' (queue / stream tuning names moved to fr_ctx_set_tuning, "
+                                                "fractalrenderer_amd/csrc/fr_tuning.h)", name);
+    }
+    return FR_OK;
+}
+
+/* Tuning knobs of the persistent queues and the survivor stream (fr_tuning.h: tests, tools/ and A/B measurements; not part
+ * of the public header).  None of them can change a pixel. */
+extern "C" int fr_ctx_set_tuning(fr_ctx* c, const char* name, int64_t value)
 {
     if (!c || !name) return fr_set_error(FR_ERR_INVALID_ARG, "ctx/name is NULL");
     if (!strcmp(name, "workgroups_per_cu")) {
@@ -179,24 +215,12 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         if (value != 0 && value != 3 && value != 4 && value != 6)
             return fr_set_error(FR_ERR_INVALID_ARG, "subtile_shape must be 0, 3 (8x8), 4 (16x4) or 6 (64x1)");
         c->tune_shape = (uint32_t)value;
-    } else if (!strcmp(name, "pool")) {
-        if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "pool must be 0 (automatic), 1 (off) or 2 (on)");
-        c->tune_pool = (uint32_t)value;
     } else if (!strcmp(name, "pool_refill_at")) {
         if (value < 0 || value > 64) return fr_set_error(FR_ERR_INVALID_ARG, "pool_refill_at must be in [0,64]");
         c->tune_pool_refill = (uint32_t)value;
-    } else if (!strcmp(name, "periodicity")) {
-        if (value < -1 || value > (1 << 20)) return fr_set_error(FR_ERR_INVALID_ARG, "periodicity must be -1 (off), 0 (automatic: on), 1 (on) or a first snapshot window in iterations");
-        c->tune_periodicity = value <= 0 ? (int32_t)value : (value == 1 ? 128 : (int32_t)((value + 15) / 16 * 16));
-    } else if (!strcmp(name, "staging")) {
-        if (value < 0 || value > 4) return fr_set_error(FR_ERR_INVALID_ARG, "staging must be 0 (automatic), 1 (single pass), 2 (block stages), 3 (tile pass + lane-pool pass) or 4 (fused: one launch)");
-        c->tune_staging = (uint32_t)value;
     } else if (!strcmp(name, "stage_first")) {
         if (value < 0 || value > (1 << 24)) return fr_set_error(FR_ERR_INVALID_ARG, "stage_first out of range");
         c->tune_stage_first = (uint32_t)value;
-    } else if (!strcmp(name, "stage_ratio")) {
-        if (value != 0 && (value < 2 || value > 64)) return fr_set_error(FR_ERR_INVALID_ARG, "stage_ratio must be 0 or in [2,64]");
-        c->tune_stage_ratio = (uint32_t)value;
     } else if (!strcmp(name, "stream_run_max")) {
         if (value < 0 || value > 1024) return fr_set_error(FR_ERR_INVALID_ARG, "stream_run_max must be in [0,1024]");
         c->tune_stream_run_max = (uint32_t)value;
@@ -206,20 +230,12 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "stream_workgroups_per_cu")) {
         if (value < 0 || value > 8) return fr_set_error(FR_ERR_INVALID_ARG, "stream_workgroups_per_cu must be in [0,8]");
         c->tune_stream_wg_per_cu = (uint32_t)value;
-    } else if (!strcmp(name, "diag_stride")) {
-        c->diag_stride = (size_t)value;               /* u64 words between the diag regions of consecutive stages */
     } else if (!strcmp(name, "probes")) {
         c->tune_probes = (uint32_t)value & 0xFu;
     } else if (!strcmp(name, "stream_probes")) {
         c->tune_stream_probes = (uint32_t)value & 0xFu;
     } else if (!strcmp(name, "stream_rotate")) {
         c->tune_stream_rotate = (uint32_t)value;
-    } else if (!strcmp(name, "tile_kernel")) {
-        if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "tile_kernel must be 0 (automatic: lean where it applies) or 1 (general)");
-        c->tune_tile_kernel = (uint32_t)value;
-    } else if (!strcmp(name, "shards")) {
-        if (value != 0 && value != 8 && value != 64) return fr_set_error(FR_ERR_INVALID_ARG, "shards must be 0 (automatic), 8 or 64");
-        c->tune_shards = (uint32_t)value;
     } else if (!strcmp(name, "regions")) {
         if (value != 0 && value != 8 && value != 64) return fr_set_error(FR_ERR_INVALID_ARG, "regions must be 0 (automatic), 8 or 64");
         c->tune_regions = (uint32_t)value;
@@ -228,10 +244,8 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
         c->tune_tile_pixels = (uint32_t)value;
     } else if (!strcmp(name, "debug_region_blocks")) {
         c->debug_region_blocks = (uint32_t)value;     /* tests only (overflow reporting); 0 = the real capacity */
-    } else if (!strcmp(name, "diag_buffer")) {
-        c->diag = (uint64_t*)(uintptr_t)value;        /* device pointer, 4 x u64 per wave of the grid; 0 = off */
     } else {
-        return fr_set_error(FR_ERR_INVALID_ARG, "unknown option '%s'", name);
+        return fr_set_error(FR_ERR_INVALID_ARG, "unknown tuning name '%s'", name);
     }
     return FR_OK;
 }
@@ -347,40 +361,12 @@ static hipError_t launch_prepare(hipStream_t s, const LaunchArgs& a, uint32_t* c
 }
 
 template <typename T, int FRACTAL>
-static hipError_t launch_pool(int shape, dim3 grid, hipStream_t s, const LaunchArgs& a)
-{
-    switch (shape) {
-    case 6: hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 6, false>), grid, dim3(kBlockThreads), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 4, false>), grid, dim3(kBlockThreads), 0, s, a); break;
-    default: hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, false>), grid, dim3(kBlockThreads), 0, s, a); break;
-    }
-    return hipGetLastError();
-}
-
-template <typename T, int FRACTAL>
 static hipError_t launch_stream_pool(dim3 grid, hipStream_t s, const LaunchArgs& a)
 {
     if (a.period_window)
-        hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, true, true>), grid, dim3(kBlockThreads), 0, s, a);
+        hipLaunchKernelGGL((pool_kernel<T, FRACTAL, true>), grid, dim3(kBlockThreads), 0, s, a);
     else
-        hipLaunchKernelGGL((pool_kernel<T, FRACTAL, 3, true, false>), grid, dim3(kBlockThreads), 0, s, a);
-    return hipGetLastError();
-}
-
-template <typename T, int FRACTAL>
-static hipError_t launch_fused(dim3 grid, hipStream_t s, const LaunchArgs& a)
-{
-    if (a.period_window)
-        hipLaunchKernelGGL((fused_kernel<T, FRACTAL, true>), grid, dim3(kBlockThreads), 0, s, a);
-    else
-        hipLaunchKernelGGL((fused_kernel<T, FRACTAL, false>), grid, dim3(kBlockThreads), 0, s, a);
-    return hipGetLastError();
-}
-
-template <typename T, int FRACTAL>
-static hipError_t launch_stream(dim3 grid, hipStream_t s, const LaunchArgs& a)
-{
-    hipLaunchKernelGGL((stream_kernel<T, FRACTAL>), grid, dim3(kBlockThreads), 0, s, a);
+        hipLaunchKernelGGL((pool_kernel<T, FRACTAL, false>), grid, dim3(kBlockThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -420,11 +406,10 @@ static int check_overflow(fr_ctx* c)
                                          "is incomplete, please report the parameters");
 }
 
-/* Cycle closing ("periodicity"): on unless switched off.  Where it takes effect: the lane-pool pass of the two-launch
- * schedule and the fused launch (PERIOD instantiations), the tile kernel when it runs samples to max_iter with 8x8
- * sub-tiles -- a one-pass frame (PERIOD instantiation) and SSAA (always compiled in).  Where it does not: the effects
- * variants, one-pass frames with 16x4 / 64x1 sub-tiles, the block-stage schedule ("staging" = 2), the fresh-pixel lane
- * pool ("pool" = 2) and Deep_Zoom -- those iterate every sample to max_iter, as the reference does. */
+/* Cycle closing ("periodicity"): on unless switched off.  Where it takes effect: the lane-pool pass (PERIOD
+ * instantiation), the tile kernel when it runs samples to max_iter with 8x8 sub-tiles -- a one-pass frame (PERIOD
+ * instantiation) and SSAA (always compiled in).  Where it does not: the effects variants, one-pass frames with 16x4 /
+ * 64x1 sub-tiles and Deep_Zoom -- those iterate every sample to max_iter, as the reference does. */
 static uint32_t period_window(const fr_ctx* c)
 {
     return c->tune_periodicity < 0 ? 0u : (c->tune_periodicity == 0 ? 128u : (uint32_t)c->tune_periodicity);
@@ -633,67 +618,53 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
     return tq;
 }
 
-/* ---- stage schedule: iteration budgets b0 < b1 < ... < max_iter ---------------------------------------
- * The tile pass runs [0, b0); pass k runs [b_{k-1}, b_k) (block stages, "staging" = 2) or [b0, max_iter)
- * (lane pool, "staging" = 3, the default).  Not staged: SSAA (samples of a pixel must meet again to be
- * averaged), the effects variants (accumulators along the whole orbit), short max_iter.  Returns the
- * number of passes; bounds[k] = upper iteration bound of pass k. */
+/* ---- stage schedule ----------------------------------------------------------------------------------
+ * Two passes -- the tile pass runs [0, b0), the lane pool [b0, max_iter) -- or one.  Not staged: SSAA (samples of a pixel
+ * must meet again to be averaged), the effects variants (accumulators along the whole orbit), short max_iter.  Returns
+ * the number of passes; bounds[k] = upper iteration bound of pass k.  (Block stream passes with x4 budgets and a fused
+ * one-launch schedule were built and measured slower everywhere: DESIGN.md section 7.) */
 static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t npx, int bounds[kMaxStages])
 {
     const int max_iter = p->max_iterations;
     int nstage = 0;
-    /* automatic = tile pass + one lane-pool pass (staging 3): measured faster than the single pass on
-     * C2 (+5 %), C3 (+30 %), C5 (+40 %), 1 % slower on C4 (profiles/r01_staging_sweeps.txt) */
-    const uint32_t mode = c->tune_staging ? c->tune_staging : kAutoStaging;
-    const bool allow = !effects && p->antialiasing_samples <= 1 && (mode == 2 || mode == 3 || mode == 4);
+    const bool allow = !effects && p->antialiasing_samples <= 1 && c->tune_staging != 1u;
     /* tile-pass budget: ~max_iter/28 rounded to the unchecked block, within [32, 192] (measured best:
      * 32 at max_iter 1024, 64 at 2048, 128-192 at 4096, flat at 16384) */
     int auto_first = ((max_iter / 28 + kFastBlock / 2) / kFastBlock) * kFastBlock;
     auto_first = auto_first < 32 ? 32 : (auto_first > 192 ? 192 : auto_first);
     const int first = c->tune_stage_first ? (int)c->tune_stage_first : auto_first;
-    const int ratio = c->tune_stage_ratio >= 2 ? (int)c->tune_stage_ratio : 4;
     /* The second pass pays off where orbits are long: below max_iter ~768 (~384 on frames above 4K) ONE pass whose
      * waves stop at their home shard is faster -- 1080p at max_iter 256: 0.061 ms against 0.109 ms, the Seahorse view
      * at 4096^2 / 256: 0.69 against 1.02 ms (nearly every pixel survives the tile pass there and is handled twice);
      * above it the two passes win by up to 35 % (profiles/r01_staging_crossover.txt).  An explicit "staging" or
-     * "stage_first" option keeps the old rule (at least 2 budgets). */
+     * "stage_first" stages whenever there is room for two budgets. */
     const int auto_min = npx > ((size_t)1 << 23) ? 384 : 768;
     const bool forced = c->tune_staging != 0 || c->tune_stage_first != 0;
     if (allow && (forced ? max_iter >= 2 * first : max_iter >= auto_min)) {
-        long long b = first - first % kFastBlock;                /* budgets are multiples of the unchecked block */
+        int b = first - first % kFastBlock;                      /* the budget is a multiple of the unchecked block */
         if (b < kFastBlock) b = kFastBlock;
-        while (b < max_iter && nstage < kMaxStages - 1) {
-            bounds[nstage++] = (int)b;
-            b *= ratio;
-            if (mode == 3 || mode == 4) break;                   /* tile stage + lane pool to max_iter */
-        }
-        /* do not leave a last stage much shorter than the one before it */
-        if (nstage >= 2 && max_iter - bounds[nstage - 1] < bounds[nstage - 1] / 4) --nstage;
+        if (b < max_iter) bounds[nstage++] = b;
     }
     bounds[nstage++] = max_iter;
     return nstage;
 }
 
-/* Survivor streams: blocks of 64 records {pixel u32, iterations done u32, nfields x T}.  Worst case: every
- * sample survives (npx/64 full blocks) + one partial block per writer wave; the regions of a stream hold
+/* Survivor stream: blocks of 64 records {pixel u32, iterations done u32, nfields x T}.  Worst case: every
+ * sample survives (npx/64 full blocks) + one partial block per writer wave; the regions of the stream hold
  * 1.5x that, so a region that fills up can spill into its neighbours.  Grow-only (happens on the first
- * render of a larger geometry, not capturable).  The default schedule (tile pass + one pool pass) writes
- * one stream; the second buffer only exists for schedules with three or more passes (4 GB less scratch
- * per context at 8192^2 fp64). */
-static int reserve_streams(fr_ctx* c, size_t npx, size_t nfields, bool f64, uint32_t writer_workgroups, int nbuffers,
-                           uint32_t nregions, uint32_t* region_blocks)
+ * render of a larger geometry, not capturable). */
+static int reserve_stream(fr_ctx* c, size_t npx, size_t nfields, bool f64, uint32_t writer_workgroups, uint32_t nregions,
+                          uint32_t* region_blocks)
 {
     const size_t block_bytes = 2 * 64 * 4 + nfields * 64 * (f64 ? 8 : 4);
     const uint32_t worst_blocks = (uint32_t)((npx + 63) / 64) + writer_workgroups * 4u + 16u;
     *region_blocks = (worst_blocks * 3u / 2u + nregions - 1) / nregions + 1u;
     const size_t need = (size_t)*region_blocks * nregions * block_bytes;
-    for (int k = 0; k < nbuffers; ++k) {
-        if (need <= c->stream_bytes[k]) continue;
-        if (c->stream_buf[k]) { (void)hipFree(c->stream_buf[k]); c->stream_buf[k] = nullptr; }
-        c->stream_bytes[k] = 0;
-        FR_HIP_TRY(hipMalloc(&c->stream_buf[k], need));
-        c->stream_bytes[k] = need;
-    }
+    if (need <= c->stream_bytes) return FR_OK;
+    if (c->stream_buf) { (void)hipFree(c->stream_buf); c->stream_buf = nullptr; }
+    c->stream_bytes = 0;
+    FR_HIP_TRY(hipMalloc(&c->stream_buf, need));
+    c->stream_bytes = need;
     return FR_OK;
 }
 
@@ -762,21 +733,17 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      * profiles/r01_region_rotation.txt: C2 0.883 -> 0.831 ms, C3 0.598 -> 0.539 ms; regions by XCD = 1) */
     const uint32_t rotate_regions = c->tune_stream_rotate == 1u ? 0u : 1u;
     const int shape = c->tune_shape ? (int)c->tune_shape : 3;
-    uint32_t stage_mode = c->tune_staging ? c->tune_staging : kAutoStaging;
-    if (stage_mode == 4u && shape != 3) stage_mode = 3u;     /* the fused kernel exists for 8x8 sub-tiles only */
-    const bool pool_stream = staged && stage_mode == 3u;
-    const bool fused = staged && stage_mode == 4u;           /* both stages in one launch, hand-off inside the wave */
 
     /* bounded, cheap items: the staged tile pass, and an unstaged pass whose samples run at most 128 updates
      * (measured at max_iter <= 32: 0.31 ms with short runs -- the queue words saturate -- 0.17 ms with long) */
     const int aa1 = p->antialiasing_samples > 1 ? p->antialiasing_samples : 1;
-    const bool bounded = (staged && !fused) || (!effects && (long long)max_iter * aa1 * aa1 <= 128);
+    const bool bounded = staged || (!effects && (long long)max_iter * aa1 * aa1 <= 128);
     /* items of moderate cost (an unstaged pass below the staging threshold): short runs as for unbounded items, but
      * the waves stop at their home shard -- the blocks of 16 sub-tiles dealt round-robin keep the shards level */
     const bool moderate = !staged && !effects && (long long)max_iter * aa1 * aa1 < 768;
     uint32_t grid = 0, waves_per_shard = 0;
     /* (fp32 only: the fp64 instantiation's 82 VGPRs leave room for 5 waves per SIMD) */
-    const bool lean_staged = !f64 && staged && !fused && !effects && p->antialiasing_samples <= 1 && shape == 3 && c->tune_tile_kernel != 1u &&
+    const bool lean_staged = !f64 && staged && !effects && p->antialiasing_samples <= 1 && shape == 3 && c->tune_tile_kernel != 1u &&
                              (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
     const QueueArgs tq = plan_tile_queue(c, W, rows_local, shape, bounded, moderate, lean_staged, &grid, &waves_per_shard);
     auto clamp_shift = [&](int v) { v += c->tune_shift_bias; return (uint32_t)(v < 0 ? 0 : (v > 31 ? 31 : v)); };
@@ -796,16 +763,15 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const uint32_t nregions = c->tune_regions ? c->tune_regions : (1u << tq.ns_log2);
     const uint32_t nregions_log2 = nregions == (uint32_t)kMaxShards ? 6u : 3u;
     uint32_t region_blocks = 0;
-    if (staged && !fused) {
-        const int st = reserve_streams(c, (size_t)rows_local * W, julia ? 2 : 4, f64, grid > sgrid ? grid : sgrid,
-                                       nstage > 2 ? 2 : 1, nregions, &region_blocks);
+    if (staged) {
+        const int st = reserve_stream(c, (size_t)rows_local * W, julia ? 2 : 4, f64, grid > sgrid ? grid : sgrid, nregions,
+                                      &region_blocks);
         if (st != FR_OK) return st;
         if (c->debug_region_blocks && c->debug_region_blocks < region_blocks) region_blocks = c->debug_region_blocks;
     }
     /* the lean tile kernel: every one-sample render without effects on 8x8 sub-tiles whose row strips (if sharded) are
      * whole sub-tile rows; "tile_kernel" = 1 keeps the general kernel (tests compare the two bitwise) */
-    const bool pool = !staged && !effects && p->antialiasing_samples <= 1 && c->tune_pool == 2;
-    const bool lean = !effects && p->antialiasing_samples <= 1 && shape == 3 && !pool && !fused && c->tune_tile_kernel != 1u &&
+    const bool lean = !effects && p->antialiasing_samples <= 1 && shape == 3 && c->tune_tile_kernel != 1u &&
                       (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
     if (lean) {
         const size_t need = ((size_t)W + H) * sizeof(double);
@@ -835,28 +801,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.q.heads = stage_heads(c, 0);
     a.i0 = 0;
     a.i1 = bounds[0];
-    if (fused) {
-        /* An interior sub-tile is 64 x (max_iter - b0) updates: claim few at a time, one at a time towards the end
-         * of the queue (what a wave holds in reserve when the queue runs dry is the tail of the launch). */
-        a.q.run_min = c->tune_run_min ? c->tune_run_min : 1u;
-        a.q.run_max = c->tune_run_max ? c->tune_run_max : 4u;
-        if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
-        a.q.run_shift = clamp_shift((int)ceil_log2(4u * waves_per_shard));
-        a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
-        if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
-        a.period_window = period_window(c);
-        a.diag = c->diag;
-        a.out.overflow = c->overflow_dev;                   /* no stream here: the word only carries the watchdog's report */
-        hipError_t ef = by_variant(fractal, f64, [&](auto t, auto f) {
-            return launch_fused<decltype(t), decltype(f)::value>(dim3(grid), stream, a); });
-        if (ef != hipSuccess) return fr_set_error(FR_ERR_HIP, "fused kernel launch failed: %s", hipGetErrorString(ef));
-        FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
-        c->have_timing = true;
-        c->last_stages = 2;
-        return FR_OK;
-    }
     if (staged) {
-        a.out.base = (uint8_t*)c->stream_buf[0];
+        a.out.base = (uint8_t*)c->stream_buf;
         a.out.n_blocks = stage_counter(c, 0);
         a.out.region_blocks = region_blocks;
         a.out.rotate = rotate_regions;
@@ -865,17 +811,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     }
     a.diag = c->diag;
     hipError_t e;
-    if (pool) {
-        /* lane pool: claims are rare (a run of sub-tiles feeds 64 lanes for many refills) */
-        a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 32u;
-        if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
-        a.q.run_min = c->tune_run_min ? c->tune_run_min : 4u;
-        a.q.run_max = c->tune_run_max ? c->tune_run_max : 16u;
-        if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
-        a.q.run_shift = clamp_shift((int)ceil_log2(4u * waves_per_shard));
-        e = by_variant(fractal, f64, [&](auto t, auto f) {
-            return launch_pool<decltype(t), decltype(f)::value>(shape, dim3(grid), stream, a); });
-    } else if (effects) {
+    if (effects) {
         e = by_variant(fractal, f64, [&](auto t, auto f) {
             constexpr int F = decltype(f)::value == 1 ? 0 : decltype(f)::value;      /* Julia has no effects variant */
             return launch_tile<decltype(t), F, true>(shape, dim3(grid), stream, a); });
@@ -892,56 +828,38 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     }
     if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "tile kernel launch failed: %s", hipGetErrorString(e));
 
-    /* ---- stream passes ------------------------------------------------------------------------------ */
-    for (int k = 1; k < nstage; ++k) {
-        a.i0 = bounds[k - 1];
-        a.i1 = bounds[k];
-        a.in.base = (uint8_t*)c->stream_buf[(k - 1) & 1];
-        a.in.n_blocks = stage_counter(c, k - 1);
-        a.in.region_blocks = region_blocks;
-        a.in.nregions = nregions;
-        a.out.nregions = nregions;
-        a.out.base = (uint8_t*)c->stream_buf[k & 1];
-        a.out.n_blocks = stage_counter(c, k);
-        a.out.region_blocks = region_blocks;
-        a.out.rotate = rotate_regions;
-        a.out.overflow = c->overflow_dev;
+    /* ---- lane-pool pass: the survivors, to max_iter ------------------------------------------------------ */
+    if (staged) {
+        a.i0 = bounds[0];
+        a.i1 = max_iter;
+        a.in = a.out;                                           /* what the tile pass wrote */
+        a.in.n_blocks = stage_counter(c, 0);
+        memset(&a.out, 0, sizeof(a.out));                       /* the pool pass runs everything out ... */
+        a.out.overflow = c->overflow_dev;                       /* ... and reports a stretch loop that will not end */
         memset(&a.q, 0, sizeof(a.q));
-        a.q.heads = stage_heads(c, k);
+        a.q.heads = stage_heads(c, 1);
         a.q.ns_log2 = nregions_log2;                            /* region r of the input stream is shard r of this queue */
-        /* a block of 64 records costs at most (i1 - i0) iterations: uniform, claim a few at a time */
         const uint32_t swps = (sgrid * 4u + nregions - 1) / nregions;
         a.q.run_shift = clamp_shift((int)ceil_log2(2u * swps));
-        a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 16u;
-        a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 2u;
+        /* a lane-pool wave holds its claimed blocks as a private reserve and only stalls for a dequeue
+         * once per reserve, so claim little and never ahead: what a wave has reserved when the queue
+         * runs dry is exactly the tail of the pass (measured: 1-3 block runs + one run prefetched left
+         * a 315 us drain on C2; a block of 64 interior records is ~60 us of work at 5 waves/SIMD) */
+        a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 1u;
+        a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 2u;
         if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
         {
             uint32_t probes = c->tune_stream_probes ? c->tune_stream_probes : (rotate_regions ? 4u : 0u);
             if (sgrid < 64u || sgrid < nregions) probes = 0;
             a.q.flags = probes << kQueueProbeShift;
         }
-        a.diag = c->diag ? c->diag + (size_t)k * c->diag_stride : nullptr;
-        if (pool_stream) {
-            a.i0 = bounds[0];
-            a.i1 = max_iter;
-            a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
-            if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
-            a.out.base = nullptr;                                   /* the pool pass runs everything out */
-            a.out.overflow = c->overflow_dev;                       /* ... and reports a stretch loop that will not end */
-            a.period_window = period_window(c);
-            /* a lane-pool wave holds its claimed blocks as a private reserve and only stalls for a dequeue
-             * once per reserve, so claim little and never ahead: what a wave has reserved when the queue
-             * runs dry is exactly the tail of the pass (measured: 1-3 block runs + one run prefetched left
-             * a 315 us drain on C2; a block of 64 interior records is ~60 us of work at 5 waves/SIMD) */
-            a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 1u;
-            a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 2u;
-            e = by_variant(fractal, f64, [&](auto t, auto f) {
-                return launch_stream_pool<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
-        } else {
-            e = by_variant(fractal, f64, [&](auto t, auto f) {
-                return launch_stream<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
-        }
-        if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "stream kernel launch failed: %s", hipGetErrorString(e));
+        a.diag = c->diag ? c->diag + c->diag_stride : nullptr;
+        a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
+        if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
+        a.period_window = period_window(c);
+        e = by_variant(fractal, f64, [&](auto t, auto f) {
+            return launch_stream_pool<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
+        if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "lane-pool kernel launch failed: %s", hipGetErrorString(e));
     }
     FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
     c->have_timing = true;
@@ -993,7 +911,10 @@ extern "C" int fr_ctx_reserve(fr_ctx* c, const fr_params* p, uint32_t W, uint32_
     if (shard && shard->nparts && shard->part >= shard->nparts)
         return fr_set_error(FR_ERR_INVALID_ARG, "shard part %u >= nparts %u", shard->part, shard->nparts);
     FR_HIP_TRY(hipSetDevice(c->device));
-    FR_HIP_TRY(hipStreamSynchronize(c->stream));           /* growing a buffer frees the old one */
+    /* growing a buffer frees the old one, which a render still in flight may be reading: wait for the context's own
+     * stream and, when the most recent render went to a caller's stream, for the event recorded behind it there */
+    FR_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->render_on_user_stream && c->have_timing) FR_HIP_TRY(hipEventSynchronize(c->ev_end));
     return enqueue_render(c, p, W, H, shard, nullptr, nullptr, nullptr, c->stream, true);
 }
 
@@ -1112,18 +1033,22 @@ static size_t export_blocks(const fr_ctx* c, size_t npx)
     return blocks > cap ? cap : (blocks < 1 ? 1 : blocks);
 }
 
+/* four pixels per thread (dword / dwordx2 stores) need a width that is a multiple of four AND an output pointer aligned
+ * for those stores -- a caller may hand in a sub-buffer at any byte offset; otherwise one pixel per thread */
 static hipError_t launch_export(const fr_ctx* c, const float4* in, uint8_t* out, uint32_t W, uint32_t H, int through_half,
                                 hipStream_t s)
 {
+    const int quads_ok = (W & 3u) == 0u && ((uintptr_t)out & 3u) == 0u;
     hipLaunchKernelGGL(export_rgb8_kernel, dim3((uint32_t)export_blocks(c, (size_t)W * H)), dim3(kBlockThreads), 0, s,
-                       in, out, (int)W, (int)H, through_half);
+                       in, out, (int)W, (int)H, through_half, quads_ok, (const float2*)c->export8_thr);
     return hipGetLastError();
 }
 static hipError_t launch_export(const fr_ctx* c, const float4* in, uint16_t* out, uint32_t W, uint32_t H, int through_half,
                                 hipStream_t s)
 {
+    const int quads_ok = (W & 3u) == 0u && ((uintptr_t)out & 7u) == 0u;
     hipLaunchKernelGGL(export_rgb16_kernel, dim3((uint32_t)export_blocks(c, (size_t)W * H)), dim3(kBlockThreads), 0, s,
-                       in, out, (int)W, (int)H, through_half);
+                       in, out, (int)W, (int)H, through_half, quads_ok);
     return hipGetLastError();
 }
 

@@ -294,6 +294,35 @@ static void palette_table_fill(int shader, int mode, fr_palette_table* t)
     }
 }
 
+/* ---- 8-bit export: exact bytes --------------------------------------------------------------------
+ * The reference's byte is (uint8)(powf(a, 1/2.2f) * 255.0f) with a = aces(v) in [0, 1] (src/vk_engine.cpp:1366-1368).
+ * As a function of a it is monotone non-decreasing (powf is; checked exhaustively, over every float of [0, 1], by
+ * tests/test_host.py::test_export8_thresholds_against_an_exhaustive_scan), so it is fully described by 255
+ * thresholds: t[b] = the smallest float whose byte is >= b, found here by bisection over the float bit patterns with
+ * the host's powf -- the libm the CPU restatement of the reference loop uses.  The export kernel keeps its fast
+ * exp2(log2 a / 2.2) estimate and corrects it by comparing a with t[estimate] and t[estimate + 1]: the bytes are then
+ * those of the powf form, for every input.  t[0] = 0, t[256] = +inf. */
+static uint32_t export8_byte(uint32_t bits)
+{
+    float a;
+    memcpy(&a, &bits, sizeof(a));
+    return (uint32_t)(powf(a, 1.0f / 2.2f) * 255.0f);
+}
+
+void fr_export8_thresholds(float t[257])
+{
+    t[0] = 0.0f;
+    for (uint32_t b = 1; b < 256; ++b) {
+        uint32_t lo = 0u, hi = 0x3F800000u;           /* byte(0.0) = 0 < b <= 255 = byte(1.0) */
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (export8_byte(mid) >= b) hi = mid; else lo = mid;
+        }
+        memcpy(&t[b], &hi, sizeof(float));
+    }
+    t[256] = INFINITY;
+}
+
 /* ---- deep-zoom reference orbit -------------------------------------------------------------------
  * DeepZoomManager::compute_reference_orbit, src/deep_zoom_system.cpp:378-424.  A single-point,
  * inherently sequential fp64 recurrence: host code in the reference and here. */

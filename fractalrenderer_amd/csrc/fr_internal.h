@@ -21,6 +21,9 @@ int fr_set_error(int status, const char* fmt, ...)
 
 int32_t fr_deep_zoom_reference_length(const fr_params* p);
 
+/* thresholds of the 8-bit export (fr_host.c): t[b] = smallest float a in [0, 1] with (uint8)(powf(a, 1/2.2f) * 255) >= b */
+void fr_export8_thresholds(float t[257]);
+
 /* ---- palette knot table: what the kernels stage into LDS ------------------------------
  * Every palette of the two shaders is "warp t, then a 5-knot piece-wise linear ramp"
  * (shaders/mandelbrot.comp:60-141, shaders/julia.comp:20-181).  The table holds the ramp

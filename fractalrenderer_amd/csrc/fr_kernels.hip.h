@@ -21,8 +21,7 @@
  *     frame balances at pixel granularity.  Sub-tile cost varies 100x (a few iterations outside the
  *     set, max_iter inside) and a 64-pixel wave runs as long as its slowest lane (25 % lane occupancy
  *     on a Julia dust): after the tile pass every work item has bounded cost, and the expensive
- *     remainder runs dense.  (stream_kernel, block stages with x4 budgets, is the first form of the
- *     second pass, kept as an option.)  PERIOD variant ("periodicity" option, the library's default): a lane whose
+ *     remainder runs dense.  PERIOD variant ("periodicity" option, the library's default): a lane whose
  *     state returns to its own snapshot is on a cycle and is retired as interior at once -- exact, the planes stay
  *     byte-identical, but fewer iterations run than the reference executes (bench.py's headline switches it off).
  *   - the iteration index is wave-uniform and lives in SGPRs; a lane that escapes records
@@ -1764,113 +1763,6 @@ tile_lean_kernel(const LaunchArgs A)
     FR_STAMP_WRITE(A, lane);
 }
 
-/* ---- stream pass ---------------------------------------------------------------------------------
- * Continues the survivors of the previous pass over iterations [A.i0, A.i1): one record per lane,
- * 64 live lanes per wave.  Finished samples are shaded and stored (scattered 16-byte stores, in
- * tile order so neighbours share lines); samples alive at A.i1 < max_iter go to A.out. */
-template <typename T, int FRACTAL>
-__global__ void __launch_bounds__(kBlockThreads)
-stream_kernel(const LaunchArgs A)
-{
-    constexpr int NF = RecFields<FRACTAL>::n;
-    constexpr size_t kBlockBytes = RingWriter<T, NF>::kBlockBytes;
-
-    __shared__ LdsBlock S;
-    __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
-    stage_constants(S, A);
-    stage_interior<T, FRACTAL>(S, A);
-    __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
-    const LogTab<T> lg = stage_log2<T>(log2_lds, A);
-
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const int max_iter = A.max_iter;
-    const T bailout = (T)S.bailout;
-    const T B2 = bailout * bailout;
-    const bool want_rgb = A.rgba != nullptr;
-    const bool want_nu = want_rgb || A.nu != nullptr;
-    const bool more = A.i1 < max_iter;
-
-    RingWriter<T, NF> writer;
-    writer.init(&rings[threadIdx.x >> 6], A.out, lane);
-
-    /* region k of the input stream is shard k of the queue; its length was written by the previous launch */
-    WaveQueue q;
-    q.init_lengths(A.q.heads, A.in.n_blocks, A.in.region_blocks, A.q.run_shift, A.q.run_min, A.q.run_max, lane, A.q.ns_log2);
-    q.set_probes(A.q.flags);
-
-    uint64_t diag_t0 = 0;
-    uint32_t diag_items = 0, diag_claims = 0;
-    if (A.diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
-
-    struct Rec { uint32_t pixel; T X, Yd, cx, cyd; };
-    auto load = [&](uint32_t region, uint32_t blk) -> Rec {
-        const uint8_t* b = A.in.base + ((size_t)region * A.in.region_blocks + blk) * kBlockBytes;
-        const T* fields = reinterpret_cast<const T*>(b + RingWriter<T, NF>::kHeaderBytes);
-        Rec r;
-        r.pixel = reinterpret_cast<const uint32_t*>(b)[lane];
-        r.X = fields[lane];
-        r.Yd = fields[64 + lane];
-        if constexpr (Form<FRACTAL>::per_sample_c) { r.cx = fields[128 + lane]; r.cyd = fields[192 + lane]; }
-        else { r.cx = T(0); r.cyd = T(0); }
-        return r;
-    };
-
-    uint32_t begin, count, cur_shard;
-    while (q.next(begin, count, cur_shard)) {
-        ++diag_claims;
-        diag_items += count;
-        Rec cur = load(cur_shard, begin);
-        for (uint32_t j = begin; j < begin + count; ++j) {
-            /* the next block's records are requested before this block is iterated */
-            Rec nxt = cur;
-            if (j + 1 < begin + count) nxt = load(cur_shard, j + 1);
-            const uint32_t pixel = cur.pixel;
-            const bool valid = pixel != kInvalidPixel;
-            Orbit<T> o;
-            /* empty lanes of a partial block: z = 0, c = 0 */
-            o.X = valid ? cur.X : T(0);
-            o.Yd = valid ? cur.Yd : T(0);
-            if constexpr (Form<FRACTAL>::per_sample_c) {
-                o.cx = valid ? cur.cx : T(0);
-                o.cyd = valid ? cur.cyd : T(0);
-            } else {
-                o.cx = valid ? (T)S.julia_cx : T(0);
-                o.cyd = valid ? T(2) * (T)S.julia_cy : T(0);
-            }
-            o.x2 = o.X * o.X;
-            o.y2d = o.Yd * o.Yd;
-            int it;
-            T r2;
-            /* survivors got here without escaping for i0 >= 32 updates: start in unchecked blocks */
-            escape_run<T, Form<FRACTAL>::abs_step>(o, B2, A.i0, A.i1, A.fast_ok != 0, true,
-                          __builtin_amdgcn_ballot_w64(!valid), it, r2);
-            const bool alive = more && valid && it >= A.i1;
-            if (more) {
-                if constexpr (Form<FRACTAL>::per_sample_c) {
-                    const T rec[NF] = {o.X, o.Yd, o.cx, o.cyd};
-                    writer.append(alive, pixel, (uint32_t)A.i1, rec);
-                } else {
-                    const T rec[NF] = {o.X, o.Yd};
-                    writer.append(alive, pixel, (uint32_t)A.i1, rec);
-                }
-            }
-            if (valid && !alive) {
-                T nu;
-                float rgb[3];
-                shade<T, FRACTAL>(*kargs(), S, lg, it, r2, want_nu, want_rgb, nu, rgb);
-                if (want_rgb && (A.flags & FR_FLAG_POST_CHAIN))
-                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
-                if (A.rgba) A.rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
-                if (A.nu) reinterpret_cast<T*>(A.nu)[pixel] = nu;
-                if (A.iter) A.iter[pixel] = it;
-            }
-            cur = nxt;
-        }
-    }
-    if (more) writer.finish();
-    diag_write(A, lane, diag_t0, diag_items, diag_claims);
-}
-
 /* A dirty unchecked stretch (some lane of `badm` escaped inside it) used to be rolled back as a whole and replayed with
  * per-update tests: the kmax updates of every OTHER lane were thrown away and run again.  Only the escaped lanes need the
  * replay -- to learn the index and |z|^2 of their escaping update; everybody else's state after the stretch is already
@@ -1899,14 +1791,14 @@ __device__ __forceinline__ void locate_escapes(T sX, T sYd, T sx2, T sy2d, const
 }
 
 /* ---- lane pool ------------------------------------------------------------------------------------
- * Persistent LANES: a lane that finishes its pixel is refilled with the next pixel of the wave's
- * reserve (pixels in tile order, claimed a run of sub-tiles at a time from the XCD-sharded queue),
+ * Persistent LANES: a lane that finishes its sample is refilled with the next survivor record of the wave's
+ * reserve (blocks of 64 records claimed a run at a time from the region queues of the survivor stream),
  * so a wave stays full whatever the spread of escape times (a 64-pixel tile of a Julia dust runs
  * 25 % full when it must wait for its slowest lane) and the frame balances at pixel granularity.
  *
- *   - wclock: iterations this wave has run (wave-uniform, SGPR).  A lane refilled at wclock = s has
- *     deadline = s + max_iter; it escapes with index  wclock - s  or is interior when wclock
- *     reaches its deadline.  The earliest deadline is kept wave-uniform, so reaching it costs one
+ *   - wclock: iterations this wave has run (wave-uniform, SGPR).  A lane refilled at wclock = s with a record that
+ *     has run d updates has deadline = s + max_iter - d; it escapes with index  wclock - (deadline - max_iter)  or is
+ *     interior when wclock reaches its deadline.  The earliest deadline is kept wave-uniform, so reaching it costs one
  *     scalar compare per iteration and nothing per lane.
  *   - unchecked blocks of 16 updates stay legal at ANY alignment: if the block is clean (no lane
  *     escaped in all 16 updates) then a lane whose deadline fell inside the block did not escape
@@ -1927,15 +1819,13 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-/* FROM_STREAM = false: lanes are refilled with fresh pixels (coordinates from the pixel index);
- * FROM_STREAM = true : lanes are refilled with survivor records of the tile pass (A.in), and run the
- *                      remaining iterations [A.i0, max_iter). */
-template <typename T, int FRACTAL, int FPW_LOG2, bool FROM_STREAM, bool PERIOD = false>
+/* Lanes are refilled with survivor records of the tile pass (A.in) and run the remaining iterations [A.i0, max_iter).
+ * (A fresh-pixel form of this kernel -- lanes refilled straight from the pixel index, no tile pass -- was the first lane
+ * pool; it lost to tile pass + pool on every workload and left the product in round 3: DESIGN.md section 7.) */
+template <typename T, int FRACTAL, bool PERIOD = false>
 __global__ void __launch_bounds__(kBlockThreads)
 pool_kernel(const LaunchArgs A)
 {
-    constexpr int FPW = 1 << FPW_LOG2;
-    constexpr int FPH = kWave / FPW;
     constexpr int NF = RecFields<FRACTAL>::n;
     constexpr size_t kBlockBytes = RingWriter<T, NF>::kBlockBytes;
 
@@ -1946,22 +1836,14 @@ pool_kernel(const LaunchArgs A)
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    /* integers straight from the kernel arguments (wave-uniform SGPRs); through LDS they would be VGPR values
-     * and everything derived from them would count as divergent */
-    const int W = A.W, H = A.H, max_iter = A.max_iter;
-    const T center_x = (T)S.center_x, center_y = (T)S.center_y, zoom = (T)S.zoom;
+    const int max_iter = A.max_iter;                     /* wave-uniform: straight from the kernel arguments */
     const T bailout = (T)S.bailout;
     const T B2 = bailout * bailout;
     const T B2x4 = T(4) * B2;
-    const T resx = (T)W, resy = (T)H;
-    const T inv_w = sizeof(T) == 8 ? (T)A.inv_w_d : (T)A.inv_w_f;
-    const T inv_h = sizeof(T) == 8 ? (T)A.inv_h_d : (T)A.inv_h_f;
-    const T aspect = sizeof(T) == 8 ? (T)A.aspect_d : (T)A.aspect_f;
     const bool want_rgb = A.rgba != nullptr;
     const bool want_nu = want_rgb || A.nu != nullptr;
     const bool fast_ok = A.fast_ok != 0;
     const uint32_t refill_at = A.pool_refill_at;
-    (void)inv_w; (void)aspect; (void)H; (void)W; (void)center_x; (void)center_y; (void)zoom; (void)resx; (void)resy; (void)inv_h;
 
     /* queue parameters, stream description and output planes are re-read from the kernel arguments where they are used
      * (kargs()): held in SGPRs across the iteration loops they were what the PERIOD variant spilled (23 SGPRs) */
@@ -2039,13 +1921,13 @@ pool_kernel(const LaunchArgs A)
             if (res_next == res_count * 64u) {
 #ifdef FR_STAMP
                 const uint64_t stq = __builtin_amdgcn_s_memtime();
-                const bool got_q = q.next<FROM_STREAM>(lane, res_begin, res_count, res_shard);
+                const bool got_q = q.next<true>(lane, res_begin, res_count, res_shard);
 #ifndef FR_STAMP_TESTED
                 st_acc[0] += __builtin_amdgcn_s_memtime() - stq;
 #endif
                 if (!got_q) {
 #else
-                if (!q.next<FROM_STREAM>(lane, res_begin, res_count, res_shard)) {
+                if (!q.next<true>(lane, res_begin, res_count, res_shard)) {
 #endif
                     dry = true;
                     /* diagnostics: when this wave found the queue dry, in 100 MHz ticks since its start (bits 32..) */
@@ -2064,7 +1946,7 @@ pool_kernel(const LaunchArgs A)
                 if (rank < n) {
                     const uint32_t t = res_next + rank;
                     const uint32_t j = res_begin + (t >> 6), l = t & 63u;
-                    if constexpr (FROM_STREAM) {
+                    {
                         /* record l of block j of region res_shard */
                         KArgs K = kargs();
                         const uint8_t* b = K->in.base + ((size_t)res_shard * K->in.region_blocks + j) * kBlockBytes;
@@ -2081,60 +1963,6 @@ pool_kernel(const LaunchArgs A)
                             o.y2d = o.Yd * o.Yd;
                             deadline = wclock + ((uint32_t)max_iter - done);
                             if constexpr (PERIOD) { refX = __builtin_nan(""); refYd = refX; cyc = 0u; }
-                        }
-                    } else {
-                        /* pixel l of sub-tile j (shard-local index) */
-                        const uint32_t blk = WaveQueue::block_of(j / kShardBlock, res_shard, A.q.ns_log2);
-                        const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
-                        const uint32_t sty = A.q.nsx_shift >= 0 ? sid >> A.q.nsx_shift : sid / A.q.nsx;
-                        const uint32_t stx = sid - sty * A.q.nsx;
-                        const int px = (int)stx * FPW + (int)(l & (FPW - 1));
-                        const int lrow = (int)sty * FPH + (int)(l >> FPW_LOG2);
-                        const bool inside = blk < A.q.n_blk && sid < A.q.n_items && px < W && lrow < A.rows_local;
-                        if (inside) {
-                            int py = lrow;
-                            if (A.nparts != 1) {
-                                const int strip = lrow / A.rows_per_strip;
-                                py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
-                            }
-                            pixel = (uint32_t)lrow * (uint32_t)W + (uint32_t)px;
-                            deadline = wclock + (uint32_t)max_iter;
-                            if constexpr (PERIOD) { refX = __builtin_nan(""); refYd = refX; cyc = 0u; }
-                            if constexpr (FRACTAL == 0) {
-                                T uvx, uvy;                       /* shaders/mandelbrot.comp:149-151 */
-                                if (A.exact_div_ok) {
-                                    uvx = div_by<T>((T)px - T(0.5) * resx, resy, inv_h);
-                                    uvy = div_by<T>((T)py - T(0.5) * resy, resy, inv_h);
-                                } else {
-                                    cold_path();
-                                    uvx = ((T)px - T(0.5) * resx) / resy;
-                                    uvy = ((T)py - T(0.5) * resy) / resy;
-                                }
-                                o.X = T(0); o.Yd = T(0); o.x2 = T(0); o.y2d = T(0);
-                                o.cx = center_x + uvx * zoom;
-                                o.cyd = T(2) * (center_y + uvy * zoom);
-                            } else {
-                                T uvx, uvy;                       /* shaders/julia.comp:325, :221-225 */
-                                if (A.exact_div_ok) {
-                                    uvx = div_by<T>((T)px, resx, inv_w);
-                                    uvy = div_by<T>((T)py, resy, inv_h);
-                                } else {
-                                    cold_path();
-                                    uvx = (T)px / resx; uvy = (T)py / resy;
-                                }
-                                const T mx = center_x + (uvx - T(0.5)) * zoom * aspect;
-                                const T myd = T(2) * (center_y + (uvy - T(0.5)) * zoom);
-                                if constexpr (FRACTAL == 1) {
-                                    o.X = mx; o.Yd = myd;
-                                    o.cx = (T)S.julia_cx;
-                                    o.cyd = T(2) * (T)S.julia_cy;
-                                } else {                          /* shaders/burning_ship.comp:322-325: the map gives c */
-                                    o.X = T(0); o.Yd = T(0);
-                                    o.cx = mx; o.cyd = myd;
-                                }
-                                o.x2 = o.X * o.X;
-                                o.y2d = o.Yd * o.Yd;
-                            }
                         }
                     }
                 }
@@ -2154,15 +1982,9 @@ pool_kernel(const LaunchArgs A)
         const uint32_t nactive = (uint32_t)__builtin_popcountll(active);
         /* a wave that can no longer refill is on the critical path of the launch: give it issue priority */
         if (dry) __builtin_amdgcn_s_setprio(3);
-        if (FROM_STREAM && A.i0 == 0) {
-            /* records carry their own progress (block-stage schedules), so deadlines are not monotone: keep the true minimum */
-            next_deadline = wclock + wave_min_u32<T>(pixel != kInvalidPixel ? deadline - wclock : 0xFFFFFFFFu);
-            have_running = true;
-        } else {
-            /* refilled lanes get the LATEST deadline (wclock + max_iter), so the earliest one only
-             * changes when it is reached: no reduction here */
-            if (!have_running) { next_deadline = wclock + (uint32_t)(max_iter - (FROM_STREAM ? A.i0 : 0)); have_running = true; }
-        }
+        /* every record has run exactly A.i0 updates, so refilled lanes get the LATEST deadline of the wave
+         * (wclock + max_iter - i0) and the earliest one only changes when it is reached: no reduction here */
+        if (!have_running) { next_deadline = wclock + (uint32_t)(max_iter - A.i0); have_running = true; }
 
         /* ---- iterate until `goal` lanes have finished ---- */
         /* How many idle lanes to wait for.  A retire + refill costs the wave about 40 updates' worth of instructions
@@ -2406,370 +2228,6 @@ pool_kernel(const LaunchArgs A)
     FR_STAMP_WRITE(A, lane);
 }
 
-/* ---- fused pass: tile stage + lane pool in ONE persistent launch, hand-off inside the wave -----------------------
- *
- * Every WAVE is both stages of the two-launch schedule (tile_kernel, then pool_kernel over the compacted survivors):
- *
- *   - POOL STATE: 64 persistent lanes, as pool_kernel: a lane holds one sample, runs it towards max_iter in the
- *     wave-uniform loops (unchecked blocks of 16 updates with rollback + tested replay), is retired (shaded, stored)
- *     when it escapes or reaches its deadline, and is refilled;
- *   - TILE STAGE: when the wave's survivor ring (LDS, wave-private, 128 records) holds fewer records than the wave
- *     has free lanes, the wave takes the next 8x8 sub-tile of its reserve (runs of sub-tiles claimed from the
- *     XCD-sharded queue, one atomicAdd per run), maps its 64 pixels, runs their first b0 updates with the
- *     wave-uniform early-out, shades and stores (coalesced, whole 128-byte lines) the pixels that escaped and
- *     appends the survivors to the ring -- while its pool lanes wait in their registers;
- *   - the free lanes are refilled from the ring (ds_reads; every record has run exactly b0 updates, so a refilled
- *     lane gets the LATEST deadline of the wave and the earliest one only changes when it is reached).
- *
- * The hand-off never leaves the wave: no survivor stream in HBM (C2: 131 MB written + read per frame, 4 GB less
- * scratch at 8192^2), no counters, no cross-workgroup visibility protocol, one launch.  What it costs: a sub-tile
- * inside the set is 64 x (max_iter - b0) updates -- one "generation" of a wave, 80 us on C2 -- and it stays with the
- * wave that claimed it, so waves end the launch with different backlogs (ring + reserve) and the last tenth of the
- * launch runs on a nearly empty chip.  Measured: its throughput phase is VALU-issue bound like
- * the two launches' pool pass, its tail is longer; the two-launch schedule stays the default for whole frames.
- * Per-lane operation sequence = tile_kernel + pool_kernel: every plane is bit-identical to theirs. */
-template <typename T, int FRACTAL, bool PERIOD>
-__global__ void __launch_bounds__(kBlockThreads)
-fused_kernel(const LaunchArgs A)
-{
-    constexpr int FPW_LOG2 = 3, FPW = 8, FPH = 8;
-    constexpr int NF = RecFields<FRACTAL>::n;
-    constexpr bool ABS = Form<FRACTAL>::abs_step;
-
-    __shared__ LdsBlock S;
-    __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
-    stage_constants(S, A);
-    stage_interior<T, FRACTAL>(S, A);
-    __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
-    const LogTab<T> lg = stage_log2<T>(log2_lds, A);
-
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const int lx = (int)(lane & (FPW - 1)), ly = (int)(lane >> FPW_LOG2);
-    const int W = A.W, max_iter = A.max_iter, b0 = A.i1;
-    const T center_x = (T)S.center_x, center_y = (T)S.center_y, zoom = (T)S.zoom;
-    const T bailout = (T)S.bailout;
-    const T B2 = bailout * bailout;
-    const T B2x4 = T(4) * B2;
-    const T resx = (T)W, resy = (T)A.H;
-    const T inv_w = sizeof(T) == 8 ? (T)A.inv_w_d : (T)A.inv_w_f;
-    const T inv_h = sizeof(T) == 8 ? (T)A.inv_h_d : (T)A.inv_h_f;
-    const T aspect = sizeof(T) == 8 ? (T)A.aspect_d : (T)A.aspect_f;
-    const bool want_rgb = A.rgba != nullptr;
-    const bool want_nu = want_rgb || A.nu != nullptr;
-    const bool fast_ok = A.fast_ok != 0;
-    const uint32_t refill_at = A.pool_refill_at;
-    const uint32_t span = (uint32_t)(max_iter - b0);         /* updates a survivor still has to run */
-    (void)inv_w; (void)aspect; (void)resx;
-
-    WaveRing<T, NF>* ring = &rings[threadIdx.x >> 6];
-    uint32_t rhead = 0, rtail = 0;                           /* wave-uniform record counters */
-
-    LeanQueue q;                 /* queue parameters and output planes re-read from the kernel arguments (kargs()) */
-    q.init();
-
-    uint64_t diag_t0 = 0;
-    uint32_t diag_items = 0, diag_claims = 0, diag_dry = 0;
-    if (A.diag) diag_t0 = __builtin_amdgcn_s_memrealtime();
-
-    /* pool state, per lane */
-    uint32_t pixel = kInvalidPixel;      /* kInvalidPixel: lane is free */
-    uint32_t fin = 0;                    /* 1: finished, waiting to be shaded and stored */
-    Orbit<T> o;
-    o.X = o.Yd = o.cx = o.cyd = o.x2 = o.y2d = T(0);
-    uint32_t deadline = 0;
-    int esc_i = 0;
-    T esc_r2 = T(0);
-    T refX = __builtin_nan(""), refYd = __builtin_nan("");
-    uint32_t cyc = 0;
-    /* pool state, wave-uniform */
-    uint32_t next_snap = 0;
-    uint32_t snap_window = A.period_window, snap_closed = 1u;
-    const uint32_t snap_cap = A.period_window > (((uint32_t)A.max_iter >> 7) << 4) ? A.period_window : (((uint32_t)A.max_iter >> 7) << 4);
-    uint32_t wclock = 0, next_deadline = 0;
-    bool have_running = false;
-    uint32_t res_next = 0, res_end = 0, res_shard = 0;       /* reserve: shard-local sub-tile indices [res_next, res_end) */
-    bool dry = false, fast = false;
-
-    for (;;) {
-        /* ---- retire: shade and store the finished lanes ---- */
-        if (__builtin_amdgcn_ballot_w64(fin != 0u) != 0ull) {
-            if (fin != 0u) {
-                T nu;
-                float rgb[3];
-                shade<T, FRACTAL>(*kargs(), S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
-                KArgs K = kargs();
-                if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
-                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
-                if (K->rgba) K->rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
-                if (K->nu) reinterpret_cast<T*>(K->nu)[pixel] = nu;
-                if (K->iter) K->iter[pixel] = esc_i;
-                pixel = kInvalidPixel;
-                fin = 0u;
-            }
-        }
-        const uint64_t freem = __builtin_amdgcn_ballot_w64(pixel == kInvalidPixel);
-        const uint32_t nfree = (uint32_t)__builtin_popcountll(freem);
-
-        /* ---- tile stage: until the ring can fill the free lanes (or the queue is dry) ---- */
-        while (!dry && rtail - rhead < nfree) {
-            if (res_next == res_end) {
-                uint32_t begin, count;
-                if (!q.next(lane, begin, count, res_shard)) {
-                    dry = true;
-                    diag_dry = A.diag ? (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0) : 0u;
-                    break;
-                }
-                res_next = begin; res_end = begin + count;
-                ++diag_claims;
-                diag_items += count;
-            }
-            const uint32_t j = res_next++;
-            const uint32_t blk = WaveQueue::block_of(j / kShardBlock, res_shard, A.q.ns_log2);
-            if (blk >= A.q.n_blk) continue;
-            const uint32_t sid = blk * kShardBlock + (j % kShardBlock);
-            if (sid >= A.q.n_items) continue;
-            const uint32_t sty = A.q.nsx_shift >= 0 ? sid >> A.q.nsx_shift : sid / A.q.nsx;
-            const uint32_t stx = sid - sty * A.q.nsx;
-            const int px = (int)stx * FPW + lx;
-            const int lrow = (int)sty * FPH + ly;
-            const bool inside = px < W && lrow < A.rows_local;
-            int py = lrow;
-            if (A.nparts != 1) {
-                const int strip = lrow / A.rows_per_strip;
-                py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
-            }
-            const uint64_t outside_mask = __builtin_amdgcn_ballot_w64(!inside);
-            const uint32_t tpixel = (uint32_t)lrow * (uint32_t)W + (uint32_t)px;
-
-            Orbit<T> t;
-            if constexpr (FRACTAL == 0) {
-                T uvx, uvy;                                   /* shaders/mandelbrot.comp:149-151 */
-                if (A.exact_div_ok) {
-                    uvx = div_by<T>((T)px - T(0.5) * resx, resy, inv_h);
-                    uvy = div_by<T>((T)py - T(0.5) * resy, resy, inv_h);
-                } else {
-                    cold_path();
-                    uvx = ((T)px - T(0.5) * resx) / resy;
-                    uvy = ((T)py - T(0.5) * resy) / resy;
-                }
-                const T cx = center_x + uvx * zoom;
-                const T cy = center_y + uvy * zoom;
-                t.X = T(0); t.Yd = T(0); t.x2 = T(0); t.y2d = T(0);
-                t.cx = inside ? cx : T(0);
-                t.cyd = inside ? T(2) * cy : T(0);
-            } else {
-                T uvx, uvy;                                   /* shaders/julia.comp:325, :221-225; burning_ship.comp:393, :322-325 */
-                if (A.exact_div_ok) {
-                    uvx = div_by<T>((T)px, resx, inv_w);
-                    uvy = div_by<T>((T)py, resy, inv_h);
-                } else {
-                    cold_path();
-                    uvx = (T)px / resx; uvy = (T)py / resy;
-                }
-                const T z0x = center_x + (uvx - T(0.5)) * zoom * aspect;
-                const T z0y = center_y + (uvy - T(0.5)) * zoom;
-                if constexpr (FRACTAL == 1) {
-                    t.X = inside ? z0x : T(0);
-                    t.Yd = inside ? T(2) * z0y : T(0);
-                    t.cx = inside ? (T)S.julia_cx : T(0);
-                    t.cyd = inside ? T(2) * (T)S.julia_cy : T(0);
-                } else {
-                    t.X = T(0); t.Yd = T(0);
-                    t.cx = inside ? z0x : T(0);
-                    t.cyd = inside ? T(2) * z0y : T(0);
-                }
-                t.x2 = t.X * t.X;
-                t.y2d = t.Yd * t.Yd;
-            }
-            int it;
-            T r2;
-            escape_run<T, ABS, false>(t, B2, 0, b0, fast_ok, false, outside_mask, it, r2);
-            const bool alive = inside && it >= b0;
-            {   /* survivors -> the wave's ring */
-                const uint64_t m = __builtin_amdgcn_ballot_w64(alive);
-                if (m != 0ull) {
-                    if (alive) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        const uint32_t slot = (rtail + rank) & (kRingSlots - 1);
-                        ring->pix[slot] = tpixel;
-                        ring->f[0][slot] = t.X;
-                        ring->f[1][slot] = t.Yd;
-                        if constexpr (NF == 4) { ring->f[2][slot] = t.cx; ring->f[3][slot] = t.cyd; }
-                    }
-                    rtail += (uint32_t)__builtin_popcountll(m);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (inside && !alive) {
-                T nu;
-                float rgb[3];
-                shade<T, FRACTAL>(*kargs(), S, lg, it, r2, want_nu, want_rgb, nu, rgb);
-                KArgs K = kargs();
-                if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
-                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
-                if (K->rgba) K->rgba[tpixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
-                if (K->nu) reinterpret_cast<T*>(K->nu)[tpixel] = nu;
-                if (K->iter) K->iter[tpixel] = it;
-            }
-        }
-
-        /* ---- refill the free lanes from the ring ---- */
-        {
-            const uint32_t avail = rtail - rhead;
-            const uint32_t n = nfree < avail ? nfree : avail;
-            if (n != 0u) {
-                __builtin_amdgcn_wave_barrier();
-                if (pixel == kInvalidPixel) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freem, 0u));
-                    if (rank < n) {
-                        const uint32_t slot = (rhead + rank) & (kRingSlots - 1);
-                        pixel = ring->pix[slot];
-                        o.X = ring->f[0][slot];
-                        o.Yd = ring->f[1][slot];
-                        if constexpr (NF == 4) { o.cx = ring->f[2][slot]; o.cyd = ring->f[3][slot]; }
-                        else { o.cx = (T)S.julia_cx; o.cyd = T(2) * (T)S.julia_cy; }
-                        o.x2 = o.X * o.X;
-                        o.y2d = o.Yd * o.Yd;
-                        deadline = wclock + span;
-                        if constexpr (PERIOD) { refX = __builtin_nan(""); refYd = refX; cyc = 0u; }
-                    }
-                }
-                rhead += n;
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        const uint64_t active = __builtin_amdgcn_ballot_w64(pixel != kInvalidPixel);
-        if (active == 0ull) break;                           /* queue dry, ring empty, every lane retired */
-        const uint32_t nactive = (uint32_t)__builtin_popcountll(active);
-        const bool last_lap = dry && rtail == rhead;         /* nothing left to refill from: run the rest out */
-        if (last_lap) __builtin_amdgcn_s_setprio(3);
-        /* refilled lanes get the LATEST deadline (wclock + span): the earliest one only changes when it is reached */
-        if (!have_running) { next_deadline = wclock + span; have_running = true; }
-
-        /* ---- iterate until `goal` lanes have finished ---- */
-        const uint32_t goal = (last_lap || refill_at > nactive) ? nactive : refill_at;
-        uint32_t newly = 0;
-        auto reach_deadline = [&](bool at_or_past) {
-            const bool running = pixel != kInvalidPixel && fin == 0u;
-            const bool hit = running && (at_or_past ? (int32_t)(wclock - deadline) >= 0 : deadline == wclock);
-            if (hit) {
-                esc_i = max_iter; esc_r2 = T(0); fin = 1u;
-                o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
-            }
-            newly += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
-            const uint32_t rel = wave_min_u32<T>((running && !hit) ? deadline - wclock : 0xFFFFFFFFu);
-            have_running = rel != 0xFFFFFFFFu;
-            next_deadline = wclock + (have_running ? rel : span);
-        };
-        auto close_cycles = [&]() {                          /* see pool_kernel */
-            const bool running = pixel != kInvalidPixel && fin == 0u;
-            const bool hit = running && cyc != 0u;
-            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
-                if (hit) {
-                    esc_i = max_iter; esc_r2 = T(0); fin = 1u; cyc = 0u;
-                    o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
-                }
-                const uint32_t nhit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
-                newly += nhit;
-                snap_closed += nhit;
-            }
-            if ((int32_t)(wclock - next_snap) >= 0) {
-                refX = o.X; refYd = o.Yd;
-                if (snap_closed == 0u && snap_window < snap_cap) snap_window <<= 1;
-                snap_closed = 0u;
-                next_snap = wclock + snap_window;
-            }
-        };
-        uint32_t clean = 0, streak = 0, dirty_run = 0;
-        const uint32_t watchdog = wclock + (uint32_t)max_iter + 4096u;       /* see pool_kernel */
-        while (newly < goal) {
-            if ((int32_t)(wclock - watchdog) > 0) {
-                if (lane == 0 && A.out.overflow) __hip_atomic_store(A.out.overflow, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (pixel != kInvalidPixel && fin == 0u) {
-                    esc_i = max_iter; esc_r2 = T(0); fin = 1u;
-                    o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
-                }
-                break;
-            }
-            if (fast) {
-                const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
-                const uint32_t reps = streak >= 6u ? 4u : (streak >= 2u ? 2u : 1u);
-                uint32_t seen = 0u;
-                for (uint32_t rep = 0; rep < reps; ++rep) {
-#pragma unroll
-                    for (int k = 0; k < kFastBlock; ++k) orbit_step<T, ABS>(o);
-                    if constexpr (PERIOD) seen |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
-                }
-                const bool bad = !(orbit_r2x4(o) <= B2x4);
-                const uint64_t badm = __builtin_amdgcn_ballot_w64(bad);
-                if (badm != 0ull) {
-                    /* dirty stretch: locate the escaped lanes' updates (locate_escapes), keep everybody else's progress */
-                    uint32_t ek; T er;
-                    locate_escapes<T, ABS>(sX, sYd, sx2, sy2d, o.cx, o.cyd, B2x4, bad, badm,
-                                                               reps * (uint32_t)kFastBlock, ek, er);
-                    if (bad) {
-                        /* an escape at or past the lane's deadline is no escape: the sample ran its max_iter updates */
-                        const int idx = (int)(wclock + ek - (deadline - (uint32_t)max_iter));
-                        esc_i = idx < max_iter ? idx : max_iter;
-                        esc_r2 = idx < max_iter ? T(0.25) * er : T(0);
-                        fin = 1u;
-                        o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
-                    }
-                    newly += (uint32_t)__builtin_popcountll(badm);
-                    streak = 0;
-                    /* escape-dense neighbourhood: per-update tests are cheaper than locating block after block */
-                    if (++dirty_run >= 2u) fast = false;
-                } else {
-                    ++streak;
-                    dirty_run = 0;
-                }
-                wclock += reps * (uint32_t)kFastBlock;
-                /* lanes at or past their deadline that are still running never escaped -> interior */
-                if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
-                /* (a lane that escaped inside the stretch is finished: close_cycles only looks at running lanes) */
-                if constexpr (PERIOD) { cyc |= seen; close_cycles(); }
-                continue;
-            }
-            uint32_t n = next_deadline - wclock;
-            if (n > (uint32_t)kFastBlock) n = (uint32_t)kFastBlock;
-            uint32_t k = 0;
-            bool escaped = false;
-            do {
-                orbit_step<T, ABS>(o);
-                const T r2x4 = orbit_r2x4(o);
-                const bool e = r2x4 > B2x4;
-                const uint64_t em = __builtin_amdgcn_ballot_w64(e);
-                ++k;
-                if (em != 0ull) {
-                    if (e) {
-                        esc_i = (int)(wclock + k - 1u - (deadline - (uint32_t)max_iter));
-                        esc_r2 = T(0.25) * r2x4;
-                        fin = 1u;
-                        o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
-                    }
-                    newly += (uint32_t)__builtin_popcountll(em);
-                    escaped = true;
-                    if (newly >= goal) n = k;
-                }
-            } while (k < n);
-            wclock += k;
-            clean = escaped ? 0u : clean + k;
-            if (wclock == next_deadline) reach_deadline(false);
-            if constexpr (PERIOD) {
-                cyc |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
-                close_cycles();
-            }
-            if (clean >= (uint32_t)kFastBlock) { fast = fast_ok; clean = 0; }
-        }
-    }
-    if (A.diag && lane == 0) {
-        const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-        uint64_t* d = A.diag + (size_t)wave_id * kDiagWords;
-        d[0] = diag_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = diag_items;
-        d[3] = (uint64_t)diag_claims | ((uint64_t)diag_dry << 32);
-    }
-}
-
 /* ---- Deep_Zoom: the reference's perturbation shader ------------------------------------------------
  * shaders/test_deep_zoom.comp restated operation for operation (fp32, float-float centre/zoom, explicit
  * fma in dd_mul_sf as the shader writes it), quirks included -- see DESIGN.md.  The reference orbit
@@ -2937,18 +2395,27 @@ deep_zoom_kernel(const DeepZoomArgs A)
 /* ---- exports: RGBA f32 -> packed RGB8 / RGB16, flipped (src/vk_engine.cpp:1344-1371, :2054-2073) ---------------------
  * HBM-bound by design: 16 B read + 3 (6) B written per pixel.  A thread converts FOUR consecutive pixels of an output
  * row -- four 16-byte loads in flight, 12 (24) output bytes stored as three dwords (dwordx2s): whole 128-byte lines per
- * wave-instruction instead of single bytes at a stride of three -- and the gamma of the 8-bit path is the hardware
- * exp2(log2 x / 2.2) (what a GLSL pow lowers to; the reference's is MSVC's powf): it differs from a correctly rounded
- * powf in the last ulp or two, i.e. in the 8-bit result only for a value within 1e-6 of a truncation edge.  Frames whose
- * width is not a multiple of four take the one-pixel-per-thread form. */
+ * wave-instruction instead of single bytes at a stride of three.  Frames whose width is not a multiple of four, and output
+ * pointers that are not dword (dwordx2) aligned, take the one-pixel-per-thread form (`quads` = 0).
+ *
+ * The 8-bit byte is EXACTLY the reference loop's (uint8)(powf(aces(v), 1/2.2f) * 255.0f): the gamma is estimated with the
+ * hardware exp2(log2 a / 2.2) (within an ulp or two of powf: the estimated byte is off by one only next to a truncation
+ * edge) and then corrected against the thresholds of the powf form -- thr[b] = {t[b], t[b + 1]}, t[b] the smallest float
+ * whose byte is >= b (fr_export8_thresholds, host libm), 2 KB staged in LDS, one ds_read_b64 and two compares per channel.
+ * aces() itself is the same IEEE operations as the host's (contraction off, correctly rounded divide). */
 __device__ __forceinline__ float half_round(float f) { return __half2float(__float2half_rn(f)); }
 
-__device__ __forceinline__ uint32_t to_u8(float f, const int through_half)
+__device__ __forceinline__ uint32_t to_u8(const float2* thr, float f, const int through_half)
 {
     if (through_half) f = half_round(f);
     f = aces(f);                                                              /* :1366 */
-    f = pow01(f, 1.0f / 2.2f);                                                /* :1367; aces() clamps to [0, 1] */
-    return (uint32_t)(f * 255.0f);                                            /* :1368 (truncation) */
+    const float est = pow01(f, 1.0f / 2.2f);                                  /* :1367; aces() clamps to [0, 1] */
+    uint32_t b = (uint32_t)(est * 255.0f);                                    /* :1368 (truncation) */
+    b = b > 255u ? 255u : b;
+    const float2 t = thr[b];
+    b -= f < t.x ? 1u : 0u;
+    b += f >= t.y ? 1u : 0u;
+    return b;
 }
 __device__ __forceinline__ uint32_t to_u16(float f, const int through_half)
 {
@@ -2958,21 +2425,25 @@ __device__ __forceinline__ uint32_t to_u16(float f, const int through_half)
 }
 
 __global__ void __launch_bounds__(kBlockThreads)
-export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8, int W, int H, int through_half)
+export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8, int W, int H, int through_half, int quads_ok,
+                   const float2* __restrict__ thr_global)
 {
+    __shared__ float2 thr[256];
+    thr[threadIdx.x] = thr_global[threadIdx.x];                               /* kBlockThreads == 256 entries */
+    __syncthreads();
     const size_t n = (size_t)W * (size_t)H;
     const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if ((W & 3) == 0) {
+    if (quads_ok) {
         const size_t quads = n >> 2, wq = (size_t)W >> 2;
         uint32_t* out = reinterpret_cast<uint32_t*>(rgb8);                    /* 12 bytes per quad: 4-byte aligned */
         for (size_t q = first; q < quads; q += stride) {
             const size_t y = q / wq, x = (q - y * wq) << 2;
             const float4* src = rgba + (size_t)(H - 1 - (int)y) * W + x;       /* :1359 flip */
             const float4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
-            const uint32_t b[12] = {to_u8(p0.x, through_half), to_u8(p0.y, through_half), to_u8(p0.z, through_half),
-                                    to_u8(p1.x, through_half), to_u8(p1.y, through_half), to_u8(p1.z, through_half),
-                                    to_u8(p2.x, through_half), to_u8(p2.y, through_half), to_u8(p2.z, through_half),
-                                    to_u8(p3.x, through_half), to_u8(p3.y, through_half), to_u8(p3.z, through_half)};
+            const uint32_t b[12] = {to_u8(thr, p0.x, through_half), to_u8(thr, p0.y, through_half), to_u8(thr, p0.z, through_half),
+                                    to_u8(thr, p1.x, through_half), to_u8(thr, p1.y, through_half), to_u8(thr, p1.z, through_half),
+                                    to_u8(thr, p2.x, through_half), to_u8(thr, p2.y, through_half), to_u8(thr, p2.z, through_half),
+                                    to_u8(thr, p3.x, through_half), to_u8(thr, p3.y, through_half), to_u8(thr, p3.z, through_half)};
             uint32_t* o = out + q * 3;
             o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
             o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
@@ -2983,18 +2454,18 @@ export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8, 
     for (size_t idx = first; idx < n; idx += stride) {
         const int y = (int)(idx / (size_t)W), x = (int)(idx - (size_t)y * W);
         const float4 v = rgba[(size_t)(H - 1 - y) * W + x];
-        rgb8[idx * 3 + 0] = (uint8_t)to_u8(v.x, through_half);
-        rgb8[idx * 3 + 1] = (uint8_t)to_u8(v.y, through_half);
-        rgb8[idx * 3 + 2] = (uint8_t)to_u8(v.z, through_half);
+        rgb8[idx * 3 + 0] = (uint8_t)to_u8(thr, v.x, through_half);
+        rgb8[idx * 3 + 1] = (uint8_t)to_u8(thr, v.y, through_half);
+        rgb8[idx * 3 + 2] = (uint8_t)to_u8(thr, v.z, through_half);
     }
 }
 
 __global__ void __launch_bounds__(kBlockThreads)
-export_rgb16_kernel(const float4* __restrict__ rgba, uint16_t* __restrict__ rgb16, int W, int H, int through_half)
+export_rgb16_kernel(const float4* __restrict__ rgba, uint16_t* __restrict__ rgb16, int W, int H, int through_half, int quads_ok)
 {
     const size_t n = (size_t)W * (size_t)H;
     const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if ((W & 3) == 0) {
+    if (quads_ok) {
         const size_t quads = n >> 2, wq = (size_t)W >> 2;
         uint2* out = reinterpret_cast<uint2*>(rgb16);                         /* 24 bytes per quad: 8-byte aligned */
         for (size_t q = first; q < quads; q += stride) {

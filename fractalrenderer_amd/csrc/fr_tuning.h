@@ -1,0 +1,43 @@
+/*
+ * fr_tuning.h -- internal: tuning knobs of the persistent queues and the survivor stream.
+ *
+ * NOT part of the drop-in boundary (include/fractalrenderer_amd.h): a caller of the library needs none of these.
+ * They exist for tests/ (which prove that no queue geometry, refill threshold or region layout can change a pixel),
+ * tools/ and A/B measurements; names and meanings may change with any build.
+ *
+ * fr_ctx_set_tuning(ctx, name, value); value 0 restores the automatic choice (made per launch from the frame geometry).
+ *   "workgroups_per_cu"  workgroups of 256 threads launched per compute unit (tile pass)
+ *   "run_max", "run_min" longest / shortest run of sub-tiles one dequeue may claim
+ *   "shift_bias"         signed change of log2 of the guided-run divisor
+ *   "stage_first"        iteration budget b0 of the tile pass (default ~max_iter/28 within [32, 192], or chosen from the
+ *                        frame's coarse escape-count sample); an explicit value also stages frames below the automatic
+ *                        max_iter threshold when max_iter >= 2 b0
+ *   "pool_refill_at"     lane pool: finished lanes wait until this many are idle (default 24)
+ *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue of the lane pool may claim
+ *   "stream_workgroups_per_cu"          workgroups per compute unit of the lane-pool pass
+ *   "probes", "stream_probes"  queue shards a wave tries before it exits, tile pass / lane-pool pass
+ *                        (1..15; 0 = automatic: 1 (2 with 64 shards) for a staged or short-orbit tile pass, 4 for the lane
+ *                        pool, all shards otherwise and on grids of fewer workgroups than shards)
+ *   "regions"            8 or 64: regions of the survivor stream (default: as many as the tile queue has shards)
+ *   "stream_rotate"      2 = survivor-stream writers rotate over the regions (equal regions), 1 = one region per XCD,
+ *                        0 = automatic (= 2)
+ *   "tile_pixels"        1 / 2 sub-tiles per trip of the lean tile kernel (0 = 2)
+ *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1 (general tile kernel)
+ *   "debug_region_blocks" caps the capacity of a survivor-stream region so that the overflow report (FR_ERR_INTERNAL)
+ *                        can be exercised; 0 = the real capacity (1.5x the worst case)
+ */
+#ifndef FR_TUNING_H
+#define FR_TUNING_H
+
+#include "fractalrenderer_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int fr_ctx_set_tuning(fr_ctx* ctx, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FR_TUNING_H */

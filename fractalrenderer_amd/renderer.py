@@ -80,8 +80,12 @@ class Renderer:
         return _capi.check(self._lib.fr_ctx_compute_units(self._ctx))
 
     def set_option(self, name: str, value: int) -> None:
-        """fr_ctx_set_option: queue tuning / diagnostics by name (0 = automatic)."""
-        _capi.check(self._lib.fr_ctx_set_option(self._ctx, name.encode(), int(value)))
+        """fr_ctx_set_option (the public names), or fr_ctx_set_tuning for the internal queue / stream tuning names of
+        csrc/fr_tuning.h (tests, tools, A/B measurements); 0 = automatic."""
+        if name in _capi.TUNING_NAMES:
+            _capi.check(self._lib.fr_ctx_set_tuning(self._ctx, name.encode(), int(value)))
+        else:
+            _capi.check(self._lib.fr_ctx_set_option(self._ctx, name.encode(), int(value)))
 
     def set_tuning(self, workgroups_per_cu: int = 0, subtiles_per_dequeue: int = 0, shape: int = 0,
                    run_min: int = 0, shift_bias: int = 0) -> None:
@@ -256,6 +260,14 @@ class Renderer:
         else:
             _capi.check(self._lib.fr_export_rgb8(self._ctx, p_in, width, height, p_out, mem, int(through_half)))
         return out
+
+
+def export8_thresholds() -> np.ndarray:
+    """fr_export8_thresholds (internal): t[b] = the smallest float32 a of [0, 1] with (uint8)(powf(a, 1/2.2f) * 255) >= b,
+    b = 0..255, and t[256] = inf -- the table the 8-bit export kernel corrects its gamma estimate against."""
+    t = (C.c_float * 257)()
+    _capi.lib().fr_export8_thresholds(t)
+    return np.frombuffer(t, dtype=np.float32).copy()
 
 
 def write_png(path: str, rgb: np.ndarray, texts=None, print_metadata: bool = False) -> None:

@@ -26,8 +26,8 @@
 extern "C" {
 #endif
 
-#define FR_VERSION_MAJOR 0
-#define FR_VERSION_MINOR 2
+#define FR_VERSION_MAJOR 1
+#define FR_VERSION_MINOR 0
 
 typedef enum fr_status {
     FR_OK               =  0,
@@ -220,57 +220,33 @@ int fr_ctx_check(fr_ctx* ctx);
  * < 0 if nothing was rendered yet. */
 float fr_ctx_last_kernel_ms(fr_ctx* ctx);
 
-/* Tuning / diagnostic options of the persistent tile queue, by name; value 0 restores the
- * automatic choice (made per launch from the frame geometry).  Names:
- *   "workgroups_per_cu"  workgroups of 256 threads launched per compute unit
- *   "run_max", "run_min" longest / shortest run of sub-tiles one dequeue may claim
- *   "shift_bias"         signed change of log2 of the guided-run divisor
- *   "pool"               2 = lane-pool kernel (lanes are refilled with the next pixel as they finish),
- *                        1 = off, 0 = automatic;  "pool_refill_at" = idle lanes that trigger a refill
- *   "staging"            4 = FUSED: tile stage and lane pool in ONE persistent launch -- a wave maps sub-tiles, runs their
- *                        first "stage_first" iterations, keeps the survivors in its own LDS ring and refills its 64
- *                        persistent lanes from it (no survivor stream in HBM; 8x8 sub-tiles only, else 3);
- *                        3 = tile pass for the first "stage_first" iterations + ONE lane-pool pass over the
- *                        compacted survivors to max_iter, 2 = tile pass + block stream passes, 1 = single pass,
- *                        0 = automatic: 3 where it applies (no SSAA, no trap/stripe effects) and pays off --
- *                        max_iterations >= 768, or >= 384 on frames above 2^23 pixels; below that one pass whose
- *                        waves stop at their home queue shard is faster (profiles/r01_staging_crossover.txt)
- *   "stage_first"        iteration budget of the tile pass (default ~max_iter/28 within [32, 192])
- *   "stage_ratio"        budget growth per stream pass (default 4)
- *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue may claim in a stream pass
- *   "stream_workgroups_per_cu"          workgroups per compute unit of the stream pass
- *   "probes", "stream_probes"  queue shards a wave tries before it exits, tile pass / stream passes
- *                        (1..15; 0 = automatic: 1 (2 with 64 shards) for a staged or short-orbit tile pass, 4 for stream
- *                        passes, all shards otherwise and on grids of fewer workgroups than shards)
- *   "shards", "regions"  8 or 64: shards of the work queue / regions of the survivor streams (each has ONE head word that
- *                        its waves update with returning atomics, ~15 ns apart).  0 = automatic: 64 (8 per XCD) for
- *                        launches whose waves stop at their home shards on grids of >= 512 workgroups, else 8; regions
- *                        follow the shards
- *   "stream_rotate"      2 = survivor-stream writers rotate over the regions (equal regions), 1 = one region
- *                        per XCD, 0 = automatic (= 2)
- *   "tile_kernel"        1 = the general tile kernel; 0 = automatic: the LEAN tile kernel (coordinate tables written by a
- *                        small launch in front of the render, two 8x8 sub-tiles per wave and trip) for every one-sample
- *                        render without effects on 8x8 sub-tiles whose row strips, if sharded, are whole sub-tile rows.
- *                        "tile_pixels" = 1 / 2 sub-tiles per trip of the lean kernel (0 = 2)
- *   "periodicity"        -1 = off, 0 = automatic (ON), 1 = on, N > 1 = on with a first snapshot window of N iterations.
- *                        Cycle closing: the kernels keep, per lane, the orbit state at the wave's last snapshot; a lane whose
- *                        state returns to it is on a cycle, can never escape, and is retired as interior at once instead
- *                        of being iterated to max_iter.  Exact, not a heuristic: the update is a deterministic function
- *                        of (z, c), so every plane stays byte-identical
- *                        (tests/test_gpu_parity.py::test_periodicity_never_changes_a_pixel); what changes is the number of
- *                        iterations executed -- the reference's shaders iterate every interior sample to max_iter (C2:
- *                        1.4x fewer, a filled Julia set 2.8x; views without attracting cycles pay ~2 % for the compares).
- *                        Takes effect in the lane-pool pass and the fused launch, and where the tile kernel itself runs
- *                        samples to max_iter (one-pass frames on 8x8 sub-tiles, SSAA); not in the effects variants, the
- *                        block-stage schedule, the fresh-pixel pool or Deep_Zoom.  bench.py's headline switches it OFF so
- *                        that its roofline is quoted on the reference's iteration count.
- *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1
- *   "debug_region_blocks" tests only: caps the capacity of a survivor-stream region so that the overflow report
- *                        (FR_ERR_INTERNAL) can be exercised; 0 = the real capacity (1.5x the worst case)
- *   "diag_buffer"        device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks,
- *                        items processed, dequeues); 0 disables.  "diag_stride" = uint64 words
- *                        between the regions of consecutive stages
- * None of them can change a pixel (tests/test_gpu_parity.py::test_tuning_variants_are_bit_identical). */
+/* Options by name; value 0 restores the automatic choice (made per launch from the frame geometry).  None of them can
+ * change a pixel (tests/test_gpu_parity.py::test_tuning_variants_are_bit_identical).
+ *   "periodicity"   -1 = off, 0 = automatic (ON), 1 = on, N > 1 = on with a first snapshot window of N iterations.
+ *                   Cycle closing: the kernels keep, per lane, the orbit state at the wave's last snapshot; a lane whose
+ *                   state returns to it is on a cycle, can never escape, and is retired as interior at once instead of
+ *                   being iterated to max_iter.  Exact, not a heuristic: the update is a deterministic function of (z, c),
+ *                   so every plane stays byte-identical (tests/test_gpu_parity.py::test_periodicity_never_changes_a_pixel);
+ *                   what changes is the number of iterations executed -- the reference's shaders iterate every interior
+ *                   sample to max_iter (C2: 1.4x fewer, a filled Julia set 2.8x; a wave that sees no cycle stops looking).
+ *                   Not in the effects variants or Deep_Zoom.  bench.py's headline switches it OFF so that its roofline
+ *                   is quoted on the reference's iteration count.
+ *   "staging"       0 = automatic, 1 = single pass (every sample runs to max_iter in the tile kernel), 3 = tile pass for
+ *                   the first b0 iterations + ONE lane-pool pass over the compacted survivors, whatever max_iter is.
+ *                   Automatic: 3 where it applies (no SSAA, no trap / stripe effects) and pays off -- max_iterations
+ *                   >= 768, or >= 384 on frames above 2^23 pixels (profiles/r01_staging_crossover.txt).
+ *   "shards"        8 or 64: shards of the work queue (each has ONE head word that its waves update with returning
+ *                   atomics, ~15 ns apart).  Automatic: 64 (8 per XCD) for launches whose waves stop at their home shards
+ *                   on grids of >= 512 workgroups, else 8.
+ *   "tile_kernel"   1 = the general tile kernel; 0 = automatic: the LEAN tile kernel (coordinate tables written by a small
+ *                   launch in front of the render, two 8x8 sub-tiles per wave and trip) for every one-sample render
+ *                   without effects whose row strips, if sharded, are whole sub-tile rows.
+ *   "diag_buffer"   device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks, items processed, dequeues);
+ *                   0 disables.  "diag_stride" = uint64 words between the tile pass's and the lane pool's regions.
+ * Changed in 1.0 (INTEGRATION.md lists the breaks): "periodicity" 0 means automatic = ON since 0.2 (it meant off in
+ * 0.1; -1 is off); "staging" 2 / 4 and the options "pool", "stage_ratio" are accepted and ignored (the schedules they
+ * selected are gone); the queue / stream tuning names moved to the internal fr_ctx_set_tuning
+ * (fractalrenderer_amd/csrc/fr_tuning.h). */
 int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
 
 /* Workgroups per launch of the most recent render on this context (bits 0-15) and its number of

@@ -494,3 +494,47 @@ void fro_export_rgb8(const float* rgba, int32_t W, int32_t H, uint8_t* rgb8, int
         }
     }
 }
+
+/* Exhaustive scan of the byte of the 8-bit export, (uint8)(powf(a, 1/2.2f) * 255.0f) (src/vk_engine.cpp:1367-1368), over
+ * EVERY float a of [0, 1] (bit patterns 0 .. 0x3F800000): first[b] = the smallest bit pattern whose byte is b
+ * (0xFFFFFFFF if no float maps to b); returns the number of places where the byte DEcreases from one float to the next
+ * (0 = the byte is monotone in a, which is what lets a threshold table describe it).  Checker only: the library builds its
+ * table by bisection (fr_export8_thresholds) and the tests hold it against this scan. */
+int64_t fro_export8_scan(uint32_t first[256])
+{
+    const float gamma = 1.0f / 2.2f;
+    const uint32_t last = 0x3F800000u;
+    const uint32_t chunk = 1u << 20;
+    const uint32_t nchunks = last / chunk + 1u;
+    int64_t violations = 0;
+    for (int b = 0; b < 256; b++) first[b] = 0xFFFFFFFFu;
+#pragma omp parallel
+    {
+        uint32_t mine[256];
+        int64_t bad = 0;
+        for (int b = 0; b < 256; b++) mine[b] = 0xFFFFFFFFu;
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t lo = c * chunk;
+            uint32_t hi = lo + chunk - 1u;
+            if (hi > last) hi = last;
+            uint32_t prev = 0;
+            if (lo > 0) { const uint32_t pb = lo - 1u; float a; memcpy(&a, &pb, 4); prev = (uint32_t)(uint8_t)(powf(a, gamma) * 255.0f); }
+            for (uint32_t bits = lo; ; bits++) {
+                float a;
+                memcpy(&a, &bits, 4);
+                const uint32_t by = (uint32_t)(uint8_t)(powf(a, gamma) * 255.0f);
+                if (by < prev) bad++;
+                if (bits < mine[by]) mine[by] = bits;
+                prev = by;
+                if (bits == hi) break;
+            }
+        }
+#pragma omp critical
+        {
+            violations += bad;
+            for (int b = 0; b < 256; b++) if (mine[b] < first[b]) first[b] = mine[b];
+        }
+    }
+    return violations;
+}

@@ -103,6 +103,10 @@ int32_t fro_reference_orbit(double cx, double cy, int32_t max_iter, double* out_
 void fro_export_rgb8(const float* rgba, int32_t W, int32_t H, uint8_t* rgb8,
                      int32_t through_half);
 
+/* byte of the 8-bit export scanned over every float of [0, 1]: first[b] = smallest bit pattern with byte b;
+ * returns the number of monotonicity violations (see fr_oracle.c) */
+int64_t fro_export8_scan(uint32_t first[256]);
+
 /* Colour stage alone: nu (as fro_render_rows returns it: doubles, fp32 values widened exactly) -> RGBA f32,
  * for the plain colourings whose colour is a function of nu (see include/fractalrenderer_amd.h,
  * fr_colorize_supported).  Applies the post chain when p->post_chain. */

@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
         L.fro_reference_orbit.restype = C.c_int32
         L.fro_reference_orbit.argtypes = [C.c_double, C.c_double, C.c_int32, C.c_void_p]
         L.fro_export_rgb8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        L.fro_export8_scan.restype = C.c_int64
+        L.fro_export8_scan.argtypes = [C.c_void_p]
         L.fro_colorize.argtypes = [C.POINTER(_FroParams), C.c_int64, C.c_void_p, C.c_void_p]
         L.fro_colorize.restype = None
         L.fro_max_threads.restype = C.c_int32
@@ -164,6 +166,13 @@ def export_rgb8(rgba: np.ndarray, through_half: bool = False) -> np.ndarray:
     out = np.empty((H, W, 3), np.uint8)
     lib().fro_export_rgb8(src.ctypes.data, W, H, out.ctypes.data, int(through_half))
     return out
+
+
+def export8_scan():
+    """(violations, first): the 8-bit export's byte scanned over every float of [0, 1] (fro_export8_scan)."""
+    first = np.empty(256, np.uint32)
+    bad = int(lib().fro_export8_scan(first.ctypes.data))
+    return bad, first
 
 
 def colorize(p: "OracleParams", nu: np.ndarray) -> np.ndarray:

@@ -326,7 +326,7 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
     p, W, H = CASES["seahorse_0008_f64"]
     base = gpu_render(fr, renderer, p, 200, 120)
     assert renderer.last_stages() == 2                     # default: tile pass + lane-pool pass
-    opts = ("staging", "stage_first", "stage_ratio", "stream_run_max", "stream_workgroups_per_cu", "pool_refill_at",
+    opts = ("staging", "stage_first", "stream_run_max", "stream_workgroups_per_cu", "pool_refill_at",
             "probes", "stream_probes", "stream_rotate", "tile_kernel", "tile_pixels", "shards", "regions")
     try:
         for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
@@ -335,25 +335,25 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
             for a, b in zip(base, cur):
                 assert np.array_equal(a, b)
         renderer.set_tuning()
-        for kw in (dict(staging=1), dict(staging=2), dict(staging=2, stage_first=16), dict(staging=2, stage_first=64, stage_ratio=2),
-                   dict(staging=2, stage_ratio=16), dict(staging=2, stage_first=512), dict(staging=2, stream_run_max=1),
+        for kw in (dict(staging=1), dict(stage_first=16), dict(stage_first=64), dict(stage_first=512), dict(stream_run_max=1),
                    dict(probes=8), dict(probes=2), dict(probes=1, stream_probes=1), dict(staging=1, probes=1),
-                   dict(staging=2, probes=3, stream_probes=2), dict(stream_rotate=1), dict(stream_rotate=1, stream_probes=1),
-                   dict(stream_rotate=2, stream_probes=8), dict(staging=2, stream_rotate=1),
-
-                   dict(staging=2, stage_first=16, stage_ratio=2, stream_workgroups_per_cu=2),
+                   dict(probes=3, stream_probes=2), dict(stream_rotate=1), dict(stream_rotate=1, stream_probes=1),
+                   dict(stream_rotate=2, stream_probes=8),
+                   dict(stage_first=16, stream_workgroups_per_cu=2),
                    dict(staging=3), dict(staging=3, stage_first=64, pool_refill_at=8), dict(staging=3, stage_first=16, pool_refill_at=64),
                    dict(staging=3, stream_run_max=1, stream_workgroups_per_cu=1), dict(staging=3, pool_refill_at=1),
+                   # retired schedule selectors (block stages, fused launch) are accepted and select the automatic schedule
+                   dict(staging=2), dict(staging=4),
                    # the general tile kernel against the lean one (the default), one and two sub-tiles per trip, 8 and 64
                    # queue shards / stream regions
                    dict(tile_kernel=1), dict(tile_pixels=1), dict(tile_pixels=2, staging=1), dict(tile_pixels=1, staging=1),
                    dict(shards=64), dict(shards=64, regions=8), dict(shards=8, regions=64), dict(shards=64, staging=1),
-                   dict(shards=64, staging=2), dict(shards=64, tile_kernel=1), dict(shards=64, staging=4),
+                   dict(shards=64, tile_kernel=1),
                    dict(shards=64, probes=1, stream_probes=1), dict(shards=64, tile_pixels=1, stream_rotate=1)):
             for k, v in kw.items():
                 renderer.set_option(k, v)
             cur = gpu_render(fr, renderer, p, 200, 120)
-            assert (renderer.last_stages() > 1) == (kw.get("staging", 3) in (2, 3, 4))
+            assert (renderer.last_stages() > 1) == (kw.get("staging", 3) != 1)
             for a, b in zip(base, cur):
                 assert np.array_equal(a, b), kw
             for k in opts:
@@ -411,17 +411,20 @@ def test_lean_tile_kernel_equals_the_general_one(fr, renderer, oracle, name):
 @pytest.mark.parametrize("name", sorted(n for n, (p, _, _) in CASES.items()
                                          if p.fractal <= 2 and p.aa <= 1 and not needs_effects(p)))
 def test_lane_pool_matches_oracle(fr, renderer, oracle, name, refill_at):
-    """The lane-pool kernel (lanes refilled with the next pixel as they finish) against the oracle and,
-    bitwise, against the tile pass."""
+    """The lane pool (lanes refilled with the next survivor record as they finish), whatever its refill threshold and
+    with a short tile pass in front of it so that most samples reach it, against the oracle and, bitwise, against the
+    single pass."""
     p, W, H = CASES[name]
     try:
         renderer.set_option("staging", 1)
         tile = gpu_render(fr, renderer, p, W, H)
-        renderer.set_option("pool", 2)
+        renderer.set_option("staging", 3)
+        renderer.set_option("stage_first", 16)
         renderer.set_option("pool_refill_at", refill_at)
         rgba, nu, it = gpu_render(fr, renderer, p, W, H)
+        assert renderer.last_stages() == (2 if p.max_iterations >= 32 else 1)
     finally:
-        renderer.set_option("pool", 0)
+        renderer.set_option("stage_first", 0)
         renderer.set_option("pool_refill_at", 0)
         renderer.set_option("staging", 0)
     ref = oracle.render(p, W, H)
@@ -439,10 +442,11 @@ def test_lane_pool_larger_frames_and_shards(fr, renderer, oracle, name):
         renderer.set_option("staging", 1)
         tile = gpu_render(fr, renderer, p, W, H)
         tile_sh = gpu_render(fr, renderer, p, W, H, shard=fr.Shard(1, 3, 8))
-        renderer.set_option("pool", 2)
+        renderer.set_option("staging", 3)
         for shape in (3, 6, 4):
             renderer.set_tuning(shape=shape)
             pool = gpu_render(fr, renderer, p, W, H)
+            assert renderer.last_stages() == 2
             for a, b in zip(tile, pool):
                 assert np.array_equal(a, b)
         renderer.set_tuning()
@@ -450,7 +454,6 @@ def test_lane_pool_larger_frames_and_shards(fr, renderer, oracle, name):
         for a, b in zip(tile_sh, pool_sh):
             assert np.array_equal(a, b)
     finally:
-        renderer.set_option("pool", 0)
         renderer.set_option("staging", 0)
         renderer.set_tuning()
 
@@ -460,8 +463,8 @@ def test_lane_pool_larger_frames_and_shards(fr, renderer, oracle, name):
                                   "julia_c_outside_bailout", "mandel_scale_offset", "ship_f32_the_ship",
                                   "ship_f64_ragged_mi2048", "ship_small_bailout_f64"])
 def test_staged_equals_single_pass(fr, renderer, oracle, name):
-    """Survivor compaction (tile pass + stream passes) against the single-pass kernel, bitwise, on a
-    frame large enough that rings wrap, blocks are partially filled and several stages run."""
+    """Survivor compaction (tile pass + lane-pool pass) against the single-pass kernel, bitwise, on a
+    frame large enough that rings wrap and blocks are partially filled."""
     p, _, _ = CASES[name]
     W, H = 333, 207
     try:
@@ -470,7 +473,7 @@ def test_staged_equals_single_pass(fr, renderer, oracle, name):
         assert renderer.last_stages() == 1
     finally:
         renderer.set_option("staging", 0)
-    for mode in (2, 3, 4, 0):              # 2: block stream passes, 3: one lane-pool pass over the survivors, 4: fused launch
+    for mode in (3, 0):                    # 3: tile pass + one lane-pool pass over the survivors whatever max_iter is
         try:
             renderer.set_option("staging", mode)
             staged = gpu_render(fr, renderer, p, W, H)
@@ -483,47 +486,22 @@ def test_staged_equals_single_pass(fr, renderer, oracle, name):
             assert np.array_equal(a, b), mode
 
 
-FUSED_CASES = sorted(n for n, (p, _, _) in CASES.items() if p.fractal in (0, 1, 2) and p.aa <= 1 and not needs_effects(p)
-                     and p.max_iterations >= 64)
-
-
-@pytest.mark.parametrize("name", FUSED_CASES)
-def test_fused_launch_matches_oracle_and_the_two_pass_schedule(fr, renderer, oracle, name):
-    """The fused launch ("staging" = 4: tile stage and lane pool in one persistent kernel, survivors handed over inside
-    the wave through its LDS ring) against the oracle, and bitwise
-    against the two-launch schedule and the single pass -- on the case's own frame and on one large enough that rings
-    wrap, reserves run dry at different times and lanes are refilled many times."""
-    p, W0, H0 = CASES[name]
-    for W, H in ((W0, H0), (333, 207)):
-        planes = {}
-        for mode in (1, 3, 4):
-            try:
-                renderer.set_option("staging", mode)
-                planes[mode] = gpu_render(fr, renderer, p, W, H)
-                assert renderer.last_stages() == (1 if mode == 1 else 2)
-            finally:
-                renderer.set_option("staging", 0)
-        for a, b, c in zip(planes[1], planes[3], planes[4]):
-            assert np.array_equal(a, c) and np.array_equal(b, c)
-        ref = oracle.render(p, W, H)
-        check_against(p, ref.iter, ref.nu, ref.rgba, *planes[4])
-
-
-def test_fused_launch_under_every_geometry(fr, renderer, oracle):
-    """Queue geometry, refill threshold, tile-stage budget, cycle closing and row-strip shards must not change a pixel of
-    the fused launch."""
+def test_two_pass_schedule_under_every_geometry(fr, renderer, oracle):
+    """Queue geometry, refill threshold, tile-pass budget, cycle closing and row-strip shards must not change a pixel of
+    the tile pass + lane-pool schedule."""
     for name in ("seahorse_0008_f64", "c3_julia_f32_centre0", "ship_f64_ragged_mi2048", "reset_view_f64"):
         p, _, _ = CASES[name]
         W, H = 280, 168
         try:
-            renderer.set_option("staging", 3)
+            renderer.set_option("staging", 1)
             base = gpu_render(fr, renderer, p, W, H)
             base_sh = gpu_render(fr, renderer, p, W, H, shard=fr.Shard(2, 3, 8))
-            renderer.set_option("staging", 4)
+            renderer.set_option("staging", 3)
             for kw in (dict(), dict(workgroups_per_cu=1), dict(workgroups_per_cu=8, run_max=1), dict(run_max=64, run_min=16),
                        dict(pool_refill_at=1), dict(pool_refill_at=64), dict(stage_first=16), dict(stage_first=48, pool_refill_at=7),
                        dict(probes=1), dict(probes=3, run_max=2), dict(periodicity=1), dict(periodicity=16, pool_refill_at=3),
-                       dict(periodicity=4096), dict(shift_bias=-4), dict(shift_bias=6)):
+                       dict(periodicity=4096), dict(shift_bias=-4), dict(shift_bias=6), dict(stream_workgroups_per_cu=1),
+                       dict(stream_run_max=8, stream_run_min=4), dict(regions=64), dict(stream_rotate=1, stream_probes=1)):
                 for k, v in kw.items():
                     renderer.set_option(k, v)
                 cur = gpu_render(fr, renderer, p, W, H)
@@ -537,22 +515,73 @@ def test_fused_launch_under_every_geometry(fr, renderer, oracle):
                     renderer.set_option(k, 0)
         finally:
             for k in ("staging", "workgroups_per_cu", "run_max", "run_min", "pool_refill_at", "stage_first", "probes",
-                      "periodicity", "shift_bias"):
+                      "periodicity", "shift_bias", "stream_workgroups_per_cu", "stream_run_max", "stream_run_min", "regions",
+                      "stream_rotate", "stream_probes"):
                 renderer.set_option(k, 0)
 
 
 def test_export_rgb8(fr, renderer, oracle):
+    """fr_export_rgb8 against the restated CPU loop of src/vk_engine.cpp:1344-1371: the BYTES are identical (the kernel's
+    fast gamma estimate is corrected against the powf thresholds, fr_export8_thresholds) -- on a rendered frame, on random
+    planes (out-of-range, negative and huge values included), on planes whose values sit within a few ulps of every
+    truncation edge, for widths that take the four-pixel and the one-pixel form, with and without the fp16 rounding."""
+    import torch
     p, W, H = CASES["c1_mandel_f64_default"]
     rgba, _, _ = gpu_render(fr, renderer, p, W, H)
-    for through_half in (False, True):
-        got = renderer.export_rgb8(rgba, W, H, through_half=through_half)
-        ref = oracle.export_rgb8(rgba, through_half=through_half)
-        d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
-        assert d.max() <= 1 and (d > 0).mean() < 2e-3       # powf may differ by an ulp at a truncation edge
-    import torch
+    rng = np.random.default_rng(8)
+    planes = [rgba]
+    for (h, w) in ((37, 64), (20, 61), (5, 1), (64, 256)):
+        x = rng.random((h, w, 4), dtype=np.float32)
+        x[..., :3] *= rng.choice(np.array([1.0, 1.0, 0.05, 3.0, 40.0], np.float32), size=(h, w, 3))
+        x[rng.random((h, w)) < 0.02] = -0.25
+        planes.append(np.ascontiguousarray(x))
+    # values next to every truncation edge: a = t[b] moved by -3..+3 ulps, pulled back through the tonemap
+    # (x = the root of aces(x) = a, refined in double), then x itself moved by -2..+2 ulps
+    t = np.array(fr.export8_thresholds()[1:256], np.float32)
+    a = (t.view(np.uint32)[:, None] + np.arange(-3, 4, dtype=np.int64)[None, :]).astype(np.uint32).view(np.float32).astype(np.float64)
+    a = np.clip(a, 0.0, 0.999)
+    # aces(x) = (x (2.51 x + 0.03)) / (x (2.43 x + 0.59) + 0.14) = a  ->  (2.51 - 2.43 a) x^2 + (0.03 - 0.59 a) x - 0.14 a = 0
+    qa, qb, qc = 2.51 - 2.43 * a, 0.03 - 0.59 * a, -0.14 * a
+    x = ((-qb + np.sqrt(qb * qb - 4 * qa * qc)) / (2 * qa)).astype(np.float32)
+    xs = (x.view(np.uint32)[..., None].astype(np.int64) + np.arange(-2, 3, dtype=np.int64)).astype(np.uint32).view(np.float32).ravel()
+    n4 = (xs.size + 11) // 12 * 12
+    edge = np.zeros(n4, np.float32); edge[:xs.size] = xs
+    edge_plane = np.ones((n4 // 12, 4, 4), np.float32)
+    edge_plane[..., :3] = edge.reshape(n4 // 12, 4, 3)
+    planes.append(edge_plane)
+    for src in planes:
+        h, w = src.shape[:2]
+        for through_half in (False, True):
+            got = renderer.export_rgb8(src, w, h, through_half=through_half)
+            ref = oracle.export_rgb8(src, through_half=through_half)
+            assert np.array_equal(got, ref), (src.shape, through_half, int((got != ref).sum()))
     dev = torch.from_numpy(rgba).cuda()
     out = renderer.export_rgb8(dev, W, H)
     assert out.is_cuda and np.array_equal(out.cpu().numpy(), renderer.export_rgb8(rgba, W, H))
+    # an output pointer at an odd byte offset (a caller's sub-buffer): the one-pixel form, same bytes
+    big = torch.zeros(W * H * 3 + 8, dtype=torch.uint8, device="cuda")
+    for off in (1, 2, 4):
+        view = big[off:off + W * H * 3].view(H, W, 3)
+        renderer.export_rgb8(dev, W, H, out=view)
+        assert torch.equal(view, out), off
+    big16 = torch.zeros(W * H * 3 + 8, dtype=torch.int16, device="cuda")
+    ref16 = renderer.export_rgb16(dev, W, H)
+    for off in (1, 2, 3):
+        view = big16[off:off + W * H * 3].view(H, W, 3)
+        renderer.export_rgb16(dev, W, H, out=view)
+        assert torch.equal(view, ref16), off
+
+
+def test_export_rgb8_full_size_plane_is_byte_exact(fr, renderer, oracle):
+    """A 4096^2 post-chained C2 frame (50 M channel values) through fr_export_rgb8 with the fp16 rounding of the
+    reference's storage image: identical to the restated CPU loop, byte for byte."""
+    import torch
+    W = H = 4096
+    rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    renderer.render(fr.FractalState(max_iterations=1024), W, H, rgba=rgba, post_chain=True)
+    got = renderer.export_rgb8(rgba, W, H, through_half=True).cpu().numpy()
+    ref = oracle.export_rgb8(rgba.cpu().numpy(), through_half=True)
+    assert np.array_equal(got, ref), int((got != ref).sum())
 
 
 def test_render_errors(fr, renderer):
@@ -604,10 +633,11 @@ def test_c2_full_size_properties(fr, renderer, oracle):
         renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
         assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba)
         renderer.set_tuning()
-        renderer.set_option("staging", 2)          # tile pass + survivor block-stream passes at full size
+        renderer.set_option("stage_first", 256)    # a long tile pass in front of the lane pool at full size
         renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
-        assert renderer.last_stages() == 4
+        assert renderer.last_stages() == 2
         assert torch.equal(it2, it) and torch.equal(nu2, nu) and torch.equal(rgba2, rgba)
+        renderer.set_option("stage_first", 0)
         renderer.set_option("staging", 1)          # single pass
         renderer.render(to_state(fr, p), W, H, rgba=rgba2, nu=nu2, iter=it2)
         assert renderer.last_stages() == 1
@@ -623,7 +653,7 @@ def test_c2_full_size_properties(fr, renderer, oracle):
                 renderer.set_option(k, 0)
     finally:
         renderer.set_tuning()
-        for k in ("staging", "tile_kernel", "shards", "regions", "tile_pixels"):
+        for k in ("staging", "stage_first", "tile_kernel", "shards", "regions", "tile_pixels"):
             renderer.set_option(k, 0)
     tot_it, tot_nu = 0, 0.0
     for part in range(8):
@@ -875,8 +905,14 @@ def test_render_frame_png_end_to_end(fr, renderer, oracle, tmp_path):
         okw = {("max_iterations" if k == "max_iterations" else k): v for k, v in kw.items()}
         ref = oracle.render(oracle.OracleParams(fractal=int(ft), precision=0, post_chain=1, **okw), W, H, planes=False)
         want = oracle.export_rgb8(ref.rgba, through_half=True)
+        # the export itself is byte-exact (test_export_rgb8); this tolerance is the RENDER's: its fp32 colour differs from
+        # the oracle's in the last ulp or two (hardware exp2 / log2 in the palette warp and the post chain's gamma)
         d = np.abs(px.astype(np.int16) - want.astype(np.int16))
         assert px.shape == (H, W, 3) and d.max() <= 1 and (d > 0).mean() < 0.02
+        # ... which the same chain applied to the library's own post-chained plane shows: identical bytes
+        rgba_gpu = np.empty((H, W, 4), np.float32)
+        renderer.render(fr.FractalState(**kw), W, H, fractal_type=ft, precision=fr.Precision.F32, rgba=rgba_gpu, post_chain=True)
+        assert np.array_equal(px, oracle.export_rgb8(rgba_gpu, through_half=True))
     assert not renderer.render_frame(fr.FractalState(max_iterations=0), 8, 8, str(tmp_path / "bad.png"))
 
 

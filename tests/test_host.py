@@ -33,7 +33,7 @@ def test_struct_layout_matches_header(fr):
     assert C.sizeof(fr._capi.fr_output) == 32 and C.sizeof(fr._capi.fr_shard) == 12
     major, minor = C.c_int(), C.c_int()
     fr.lib().fr_version(C.byref(major), C.byref(minor))
-    assert (major.value, minor.value) == (0, 2)
+    assert (major.value, minor.value) == (1, 0)
 
 
 def test_no_device_fails_loudly(fr):
@@ -489,6 +489,24 @@ def test_plain_c_client_host_entry_points(fr, golden, tmp_path):
     assert out.returncode == 0 and out.stdout.strip() == "host ok", out.stderr
 
 
+def test_export8_thresholds_against_an_exhaustive_scan(fr, oracle):
+    """The 8-bit export kernel corrects its gamma estimate against 255 thresholds t[b] = the smallest float of [0, 1]
+    whose byte (uint8)(powf(a, 1/2.2f) * 255) is >= b, which the library finds by bisection.  That is only a description
+    of the byte if the byte is monotone in a: the checker scans EVERY float of [0, 1] (1 065 353 217 of them) with the
+    restated expression of src/vk_engine.cpp:1367-1368, requires zero decreases and the same thresholds."""
+    bad, first = oracle.export8_scan()
+    assert bad == 0
+    assert first[0] == 0 and (first != 0xFFFFFFFF).all()            # every byte value occurs
+    assert (np.diff(first.astype(np.int64)) > 0).all()
+    t = fr.export8_thresholds()
+    assert t.shape == (257,) and t[0] == 0.0 and np.isinf(t[256])
+    assert np.array_equal(t[:256].view(np.uint32), first)
+    # sanity of the table's values in double: the threshold's byte is b, its predecessor's is below b
+    below = (t[1:256].view(np.uint32) - 1).view(np.float32)
+    assert (np.float32(255.0) * np.power(t[1:256].astype(np.float64), 1 / 2.2) >= np.arange(1, 256) - 1e-3).all()
+    assert (np.float32(255.0) * np.power(below.astype(np.float64), 1 / 2.2) < np.arange(1, 256) + 1e-3).all()
+
+
 def test_hot_kernels_keep_their_register_budget(fr):
     """The launcher sizes its persistent grids for a resident set (tile pass 5, lane pool 6 workgroups of 4 waves per
     CU): a change that pushes a hot kernel over its VGPR budget silently leaves workgroups non-resident (an
@@ -518,19 +536,17 @@ def test_hot_kernels_keep_their_register_budget(fr):
     budget = {   # mangled name: (max VGPRs, min waves/SIMD, max SGPR spills)
         # lane pool: queue parameters, stream description and output planes are re-read from the kernel arguments where
         # they are used (kargs()), so nothing spills -- v_readlane / v_writelane are VALU issue slots
-        "_ZN2fr11pool_kernelIdLi0ELi3ELb1ELb0EEEvNS_10LaunchArgsE": (80, 6, 0),    # fp64 Mandelbrot lane pool (C2/C4/C5)
-        "_ZN2fr11pool_kernelIdLi0ELi3ELb1ELb1EEEvNS_10LaunchArgsE": (80, 6, 0),    # ... with cycle closing (the default)
-        "_ZN2fr11pool_kernelIfLi1ELi3ELb1ELb0EEEvNS_10LaunchArgsE": (64, 6, 0),    # fp32 Julia lane pool (C3)
-        "_ZN2fr11pool_kernelIfLi1ELi3ELb1ELb1EEEvNS_10LaunchArgsE": (64, 6, 0),    # ... with cycle closing (the default)
+        "_ZN2fr11pool_kernelIdLi0ELb0EEEvNS_10LaunchArgsE": (80, 6, 0),    # fp64 Mandelbrot lane pool (C2/C4/C5)
+        "_ZN2fr11pool_kernelIdLi0ELb1EEEvNS_10LaunchArgsE": (80, 6, 0),    # ... with cycle closing (the default)
+        "_ZN2fr11pool_kernelIfLi1ELb0EEEvNS_10LaunchArgsE": (64, 6, 0),    # fp32 Julia lane pool (C3)
+        "_ZN2fr11pool_kernelIfLi1ELb1EEEvNS_10LaunchArgsE": (64, 6, 0),    # ... with cycle closing (the default)
         # lean tile kernel, two sub-tiles per trip (the default tile pass): 5 workgroups per CU = 5 waves per SIMD
         "_ZN2fr16tile_lean_kernelIdLi0ELb0ELi2EEEvNS_10LaunchArgsE": (96, 5, 16),  # fp64 Mandelbrot, staged (C2/C4/C5)
         "_ZN2fr16tile_lean_kernelIdLi0ELb1ELi2EEEvNS_10LaunchArgsE": (96, 5, 16),  # one-pass frames (C1), cycle closing
         "_ZN2fr16tile_lean_kernelIfLi1ELb0ELi2EEEvNS_10LaunchArgsE": (64, 6, 0),   # fp32 Julia (C3): 6 workgroups per CU
         "_ZN2fr16tile_lean_kernelIdLi0ELb0ELi1EEEvNS_10LaunchArgsE": (64, 5, 16),   # one sub-tile per trip
-        # general tile kernel (SSAA, other sub-tile shapes, strips that are not whole sub-tile rows), fused launch
+        # general tile kernel (SSAA, other sub-tile shapes, strips that are not whole sub-tile rows)
         "_ZN2fr11tile_kernelIdLi0ELi3ELb0ELb0ELb1EEEvNS_10LaunchArgsE": (96, 5, 48),
-        "_ZN2fr12fused_kernelIdLi0ELb0EEEvNS_10LaunchArgsE": (96, 5, 48),          # fused launch ("staging" = 4)
-        "_ZN2fr12fused_kernelIdLi0ELb1EEEvNS_10LaunchArgsE": (96, 5, 48),
         "_ZN2fr11tile_kernelIdLi0ELi3ELb0ELb0ELb0EEEvNS_10LaunchArgsE": (96, 5, 48),
         "_ZN2fr11tile_kernelIfLi1ELi3ELb0ELb0ELb0EEEvNS_10LaunchArgsE": (64, 5, 24),
         # the effects variant (orbit trap / stripes): its fp64 atan2 + sin epilogue holds it at 3 waves per SIMD

@@ -17,5 +17,3 @@ for l in open(sys.argv[1]):
 P
 echo "== per-launch durations (tools/tile_time.py): defaults | general tile kernel, 8 shards"
 python3 tools/tile_time.py 15 c2 c2:tile_kernel=1,shards=8 c3 c3:tile_kernel=1,shards=8 c5 c5:tile_kernel=1,shards=8 far far:tile_kernel=1,shards=8 far:plane=iter far:plane=iter,tile_kernel=1,shards=8 uhd1k uhd1k:tile_kernel=1,shards=8 2>/dev/null
-echo "== fused launch (staging=4) against tile pass + lane pool (3)"
-for w in c2 c3 c5 hd1k; do python3 tools/sweep_opts.py $w 10 "periodicity=-1,staging=3" "periodicity=-1,staging=4" 2>/dev/null; done

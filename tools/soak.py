@@ -41,7 +41,7 @@ for trial in range(trials):
     ref = oracle.render(p, W, H)
     tune = {}
     if trial % 2:
-        tune = {"staging": int(rng.choice([0, 1, 2, 3, 4])), "pool_refill_at": int(rng.choice([0, 1, 8, 40, 64])),
+        tune = {"staging": int(rng.choice([0, 1, 3])), "pool_refill_at": int(rng.choice([0, 1, 8, 40, 64])),
                 "probes": int(rng.choice([0, 1, 2, 8])), "stream_probes": int(rng.choice([0, 1, 4, 8])), "stream_rotate": int(rng.choice([0, 1, 2])),
                 "stage_first": int(rng.choice([0, 16, 48, 160])), "subtile_shape": int(rng.choice([0, 3, 4, 6])), "workgroups_per_cu": int(rng.choice([0, 1, 3, 7]))}
     tune["periodicity"] = int(rng.choice([-1, 0, 1, 16, 64, 1000]))            # exact cycle closing: never changes a pixel

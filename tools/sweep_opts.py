@@ -6,8 +6,8 @@ sys.path.insert(0, ROOT)
 import torch
 import fractalrenderer_amd as fr
 from bench import WORKLOADS
-ALL = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "subtile_shape", "staging", "stage_first", "stage_ratio",
-       "stream_run_max", "stream_run_min", "stream_workgroups_per_cu", "pool", "pool_refill_at", 
+ALL = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "subtile_shape", "staging", "stage_first",
+       "stream_run_max", "stream_run_min", "stream_workgroups_per_cu", "pool_refill_at", 
        "probes", "stream_probes", "stream_rotate", "periodicity", "tile_kernel", "tile_pixels", "shards", "regions")
 name, rounds = sys.argv[1], int(sys.argv[2])
 variants = sys.argv[3:] or [""]
