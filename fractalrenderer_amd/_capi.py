@@ -25,6 +25,13 @@ FR_ERR_INTERNAL = -8
 FR_MEM_DEVICE = 0
 FR_MEM_HOST = 1
 
+FR_LAYOUT_PACKED = 0
+FR_LAYOUT_FRAME = 1
+
+FR_GATHER_AUTO = 0
+FR_GATHER_PEER = 1
+FR_GATHER_RCCL = 2
+
 FR_PRECISION_F32 = 0
 FR_PRECISION_F64 = 1
 
@@ -48,7 +55,7 @@ class fr_params(C.Structure):
 
 
 class fr_output(C.Structure):
-    _fields_ = [("rgba", C.c_void_p), ("nu", C.c_void_p), ("iter", C.c_void_p), ("memory", C.c_int32)]
+    _fields_ = [("rgba", C.c_void_p), ("nu", C.c_void_p), ("iter", C.c_void_p), ("memory", C.c_int32), ("layout", C.c_int32)]
 
 
 class fr_shard(C.Structure):
@@ -89,6 +96,16 @@ SIGNATURES = {
                                         _P(fr_output), C.c_void_p]),
     "fr_ctx_reserve": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, _P(fr_shard)]),
     "fr_ctx_check": (C.c_int, [C.c_void_p]),
+    "fr_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "fr_node_create": (C.c_int, [_P(C.c_int), C.c_int, _P(C.c_void_p)]),
+    "fr_node_destroy": (None, [C.c_void_p]),
+    "fr_node_device_count": (C.c_int, [C.c_void_p]),
+    "fr_node_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "fr_node_render": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, C.c_int, _P(fr_output)]),
+    "fr_node_render_async": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, C.c_int, _P(fr_output)]),
+    "fr_node_wait": (C.c_int, [C.c_void_p]),
+    "fr_node_last_gather": (C.c_int, [C.c_void_p]),
+    "fr_node_last_kernel_ms": (C.c_float, [C.c_void_p, C.c_int]),
     "fr_ctx_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "fr_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "fr_ctx_last_grid": (C.c_int, [C.c_void_p]),
@@ -133,6 +150,7 @@ SIGNATURES = {
 INTERNAL_SIGNATURES = {
     "fr_ctx_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "fr_export8_thresholds": (None, [_P(C.c_float)]),          # fr_internal.h: byte thresholds of the 8-bit export
+    "fr_node_rccl_selftest": (C.c_int, [C.c_int, C.c_size_t, _P(C.c_int)]),
 }
 PUBLIC_OPTIONS = ("periodicity", "staging", "shards", "tile_kernel", "diag_buffer", "diag_stride")
 TUNING_NAMES = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "stage_first", "pool_refill_at", "stream_run_max",

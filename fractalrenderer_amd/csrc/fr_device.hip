@@ -449,7 +449,8 @@ static int reserve_orbit(fr_ctx* c, size_t need)
 }
 
 static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* norm,
-                             uint32_t rows_local, float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only)
+                             uint32_t rows_local, float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only,
+                             bool out_frame)
 {
     const int32_t max_iter = p->max_iterations;
     int32_t ref_iter = 0;
@@ -477,6 +478,7 @@ static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t
     a.palette_mode = p->palette_mode; a.max_iter = max_iter; a.ref_iter = ref_iter;
     a.W = (int32_t)W; a.H = (int32_t)H; a.rows_local = (int32_t)rows_local;
     a.part = (int32_t)norm->part; a.nparts = (int32_t)norm->nparts; a.rows_per_strip = (int32_t)norm->rows_per_strip;
+    a.out_frame = out_frame ? 1 : 0;
     a.orbit = reinterpret_cast<const float2*>(c->orbit_dev);
     a.rgba = reinterpret_cast<float4*>(rgba); a.nu = (float*)nu; a.iter = iter;
 
@@ -671,7 +673,8 @@ static int reserve_stream(fr_ctx* c, size_t npx, size_t nfields, bool f64, uint3
 /* reserve_only: do everything a render of this geometry would do BEFORE its first launch -- grow the survivor streams,
  * the Deep_Zoom orbit buffers, fill the exact-division cache -- and stop (fr_ctx_reserve). */
 static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* shard,
-                          float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only = false)
+                          float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only = false,
+                          bool out_frame = false)
 {
     if (!reserve_only) {
         const int ov = check_overflow(c);          /* of an earlier asynchronous render nobody has asked about */
@@ -687,7 +690,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const uint32_t rows_local = fr_shard_rows(&norm, H);
     if (rows_local == 0) return FR_OK;           /* this part owns no rows */
     if (p->fractal_type == FR_FRACTAL_DEEP_ZOOM)
-        return enqueue_deep_zoom(c, p, W, H, &norm, rows_local, rgba, nu, iter, stream, reserve_only);
+        return enqueue_deep_zoom(c, p, W, H, &norm, rows_local, rgba, nu, iter, stream, reserve_only, out_frame);
 
     const int fractal = p->fractal_type;                      /* 0 Mandelbrot, 1 Julia, 2 Burning Ship */
     const bool julia = fractal == FR_FRACTAL_JULIA;
@@ -701,6 +704,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.W = (int32_t)W; a.H = (int32_t)H;
     a.rows_local = (int32_t)rows_local;
     a.part = (int32_t)norm.part; a.nparts = (int32_t)norm.nparts; a.rows_per_strip = (int32_t)norm.rows_per_strip;
+    a.out_frame = out_frame ? 1 : 0;
     a.rgba = reinterpret_cast<float4*>(rgba);
     a.nu = nu; a.iter = iter;
     a.log2_tab = c->log2_tab;
@@ -873,6 +877,10 @@ static int check_common(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, c
     if (!p || !out) return fr_set_error(FR_ERR_INVALID_ARG, "params/out is NULL");
     int st = fr_params_validate(p, W, H);
     if (st != FR_OK) return st;
+    if (out->layout != FR_LAYOUT_PACKED && out->layout != FR_LAYOUT_FRAME)
+        return fr_set_error(FR_ERR_INVALID_ARG, "unknown fr_output.layout %d", out->layout);
+    if (out->layout == FR_LAYOUT_FRAME && out->memory != FR_MEM_DEVICE)
+        return fr_set_error(FR_ERR_INVALID_ARG, "FR_LAYOUT_FRAME needs FR_MEM_DEVICE planes");
     return FR_OK;
 }
 
@@ -898,7 +906,7 @@ extern "C" int fr_render_shard_async(fr_ctx* c, const fr_params* p, uint32_t W, 
     if (st <= 0) return st;
     FR_HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    st = enqueue_render(c, p, W, H, shard, out->rgba, out->nu, out->iter, s);
+    st = enqueue_render(c, p, W, H, shard, out->rgba, out->nu, out->iter, s, false, out->layout == FR_LAYOUT_FRAME);
     if (st == FR_OK) c->render_on_user_stream = s != c->stream;
     return st;
 }
@@ -924,6 +932,17 @@ extern "C" int fr_ctx_check(fr_ctx* c)
     return check_overflow(c);
 }
 
+extern "C" int fr_ctx_synchronize(fr_ctx* c)
+{
+    if (!c) return fr_set_error(FR_ERR_INVALID_ARG, "ctx is NULL");
+    FR_HIP_TRY(hipSetDevice(c->device));
+    FR_HIP_TRY(hipStreamSynchronize(c->stream));
+    return check_overflow(c);
+}
+
+extern "C" void* fr_ctx_stream_handle(fr_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int fr_ctx_device(const fr_ctx* c) { return c ? c->device : -1; }
+
 extern "C" int fr_render_shard(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
                                const fr_shard* shard, const fr_output* out)
 {
@@ -934,7 +953,7 @@ extern "C" int fr_render_shard(fr_ctx* c, const fr_params* p, uint32_t W, uint32
     FR_HIP_TRY(hipSetDevice(c->device));
 
     if (out->memory == FR_MEM_DEVICE) {
-        st = enqueue_render(c, p, W, H, shard, out->rgba, out->nu, out->iter, c->stream);
+        st = enqueue_render(c, p, W, H, shard, out->rgba, out->nu, out->iter, c->stream, false, out->layout == FR_LAYOUT_FRAME);
         if (st != FR_OK) return st;
         c->render_on_user_stream = false;
         FR_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1039,16 +1058,22 @@ static hipError_t launch_export(const fr_ctx* c, const float4* in, uint8_t* out,
                                 hipStream_t s)
 {
     const int quads_ok = (W & 3u) == 0u && ((uintptr_t)out & 3u) == 0u;
-    hipLaunchKernelGGL(export_rgb8_kernel, dim3((uint32_t)export_blocks(c, (size_t)W * H)), dim3(kBlockThreads), 0, s,
-                       in, out, (int)W, (int)H, through_half, quads_ok, (const float2*)c->export8_thr);
+    const dim3 grid((uint32_t)export_blocks(c, (size_t)W * H));
+    if (through_half)
+        hipLaunchKernelGGL(export_rgb8_kernel<true>, grid, dim3(kBlockThreads), 0, s, in, out, (int)W, (int)H, quads_ok, (const float2*)c->export8_thr);
+    else
+        hipLaunchKernelGGL(export_rgb8_kernel<false>, grid, dim3(kBlockThreads), 0, s, in, out, (int)W, (int)H, quads_ok, (const float2*)c->export8_thr);
     return hipGetLastError();
 }
 static hipError_t launch_export(const fr_ctx* c, const float4* in, uint16_t* out, uint32_t W, uint32_t H, int through_half,
                                 hipStream_t s)
 {
     const int quads_ok = (W & 3u) == 0u && ((uintptr_t)out & 7u) == 0u;
-    hipLaunchKernelGGL(export_rgb16_kernel, dim3((uint32_t)export_blocks(c, (size_t)W * H)), dim3(kBlockThreads), 0, s,
-                       in, out, (int)W, (int)H, through_half, quads_ok);
+    const dim3 grid((uint32_t)export_blocks(c, (size_t)W * H));
+    if (through_half)
+        hipLaunchKernelGGL(export_rgb16_kernel<true>, grid, dim3(kBlockThreads), 0, s, in, out, (int)W, (int)H, quads_ok);
+    else
+        hipLaunchKernelGGL(export_rgb16_kernel<false>, grid, dim3(kBlockThreads), 0, s, in, out, (int)W, (int)H, quads_ok);
     return hipGetLastError();
 }
 
@@ -1057,7 +1082,8 @@ template <typename OUT>
 static int export_sync(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H, OUT* out, int32_t memory, int32_t through_half,
                        const char* what)
 {
-    if (!c || !rgba || !out || W == 0 || H == 0) return fr_set_error(FR_ERR_INVALID_ARG, "%s: bad argument", what);
+    if (!c || !rgba || !out || W == 0 || H == 0 || (uint64_t)W * H >= (1ull << 31))
+        return fr_set_error(FR_ERR_INVALID_ARG, "%s: bad argument (NULL pointer, empty frame or 2^31 pixels and more)", what);
     FR_HIP_TRY(hipSetDevice(c->device));
     const size_t npx = (size_t)W * H;
     const float4* d_in = reinterpret_cast<const float4*>(rgba);
@@ -1090,7 +1116,8 @@ template <typename OUT>
 static int export_async(fr_ctx* c, const float* rgba, uint32_t W, uint32_t H, OUT* out, int32_t through_half, void* hip_stream,
                         const char* what)
 {
-    if (!c || !rgba || !out || W == 0 || H == 0) return fr_set_error(FR_ERR_INVALID_ARG, "%s: bad argument", what);
+    if (!c || !rgba || !out || W == 0 || H == 0 || (uint64_t)W * H >= (1ull << 31))
+        return fr_set_error(FR_ERR_INVALID_ARG, "%s: bad argument (NULL pointer, empty frame or 2^31 pixels and more)", what);
     FR_HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     if (!hip_stream) FR_HIP_TRY(order_after_last_render(c, s));

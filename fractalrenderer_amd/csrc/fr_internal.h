@@ -21,6 +21,10 @@ int fr_set_error(int status, const char* fmt, ...)
 
 int32_t fr_deep_zoom_reference_length(const fr_params* p);
 
+/* the context's own stream (hipStream_t) and device ordinal: fr_node.cpp orders RCCL transfers behind the renders */
+void* fr_ctx_stream_handle(fr_ctx* ctx);
+int   fr_ctx_device(const fr_ctx* ctx);
+
 /* thresholds of the 8-bit export (fr_host.c): t[b] = smallest float a in [0, 1] with (uint8)(powf(a, 1/2.2f) * 255) >= b */
 void fr_export8_thresholds(float t[257]);
 

@@ -110,6 +110,8 @@ struct LaunchArgs {
     int32_t W, H;                /* whole frame                                  */
     int32_t rows_local;          /* rows this part renders                       */
     int32_t part, nparts, rows_per_strip;
+    int32_t out_frame;           /* 1: the output planes are WHOLE-FRAME planes and the part's rows are stored in place
+                                  * (frame row py), 0: the part's rows are stored packed (local row) -- FR_LAYOUT_FRAME */
     int32_t aa;
     /* colouring */
     int32_t palette_mode;
@@ -1153,7 +1155,7 @@ tile_kernel(const LaunchArgs A)
                 py = (strip * A.nparts + A.part) * A.rows_per_strip + (lrow - strip * A.rows_per_strip);
             }
             const uint64_t outside_mask = __builtin_amdgcn_ballot_w64(!inside);
-            const uint32_t pixel = (uint32_t)lrow * (uint32_t)W + (uint32_t)px;
+            const uint32_t pixel = (uint32_t)(A.out_frame ? py : lrow) * (uint32_t)W + (uint32_t)px;
 
             float acc[3] = {0.0f, 0.0f, 0.0f};
             T first_nu = T(0);
@@ -1617,6 +1619,7 @@ tile_lean_kernel(const LaunchArgs A)
     const T* __restrict__ xs = reinterpret_cast<const T*>(A.xs);
     const T* __restrict__ yds = reinterpret_cast<const T*>(A.yds);
     const uint32_t W = (uint32_t)A.W, rows_local = (uint32_t)A.rows_local, nsx = A.q.nsx;
+    const bool out_frame = A.out_frame != 0;
 
     LeanWriter<T, NF> writer;
     writer.init();
@@ -1684,7 +1687,7 @@ tile_lean_kernel(const LaunchArgs A)
                     const uint32_t px = (stx + (uint32_t)p) * 8u + lx;
                     inside[p] = (uint32_t)p < np && px < W && row_in;
                     lane_off[p] = !inside[p];
-                    pixel[p] = lrow * W + px;
+                    pixel[p] = (out_frame ? py0 + ly : lrow) * W + px;       /* where the pixel's planes entries are */
                     const T tx = xs[inside[p] ? px : 0u];
                     if constexpr (FRACTAL == 1) {
                         o[p].X = tx; o[p].Yd = tyd;
@@ -2237,7 +2240,7 @@ struct DeepZoomArgs {
     float cx_hi, cx_lo, cy_hi, cy_lo, zoom_hi, zoom_lo;
     float bailout, color_offset, color_scale;
     int32_t palette_mode, max_iter, ref_iter;
-    int32_t W, H, rows_local, part, nparts, rows_per_strip;
+    int32_t W, H, rows_local, part, nparts, rows_per_strip, out_frame;
     const float2* orbit;
     float4* rgba;
     float* nu;
@@ -2383,7 +2386,7 @@ deep_zoom_kernel(const DeepZoomArgs A)
                 float smooth = (float)max_iter;
                 if (esc_i < max_iter && !((float)esc_i >= (float)max_iter - 0.5f))      /* :76 */
                     deep_zoom_color(A, (float)esc_i, ezx, ezy, rgb, smooth);
-                const size_t o = (size_t)lrow * (size_t)W + (size_t)px;
+                const size_t o = (size_t)(A.out_frame ? py : lrow) * (size_t)W + (size_t)px;
                 if (A.rgba) A.rgba[o] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
                 if (A.nu) A.nu[o] = smooth;
                 if (A.iter) A.iter[o] = esc_i;
@@ -2405,90 +2408,115 @@ deep_zoom_kernel(const DeepZoomArgs A)
  * aces() itself is the same IEEE operations as the host's (contraction off, correctly rounded divide). */
 __device__ __forceinline__ float half_round(float f) { return __half2float(__float2half_rn(f)); }
 
-__device__ __forceinline__ uint32_t to_u8(const float2* thr, float f, const int through_half)
+/* aces() with the clamp as ONE v_med3_f32 instead of two compares and two selects.  It differs from clamp01() only for
+ * -0.0 (kept by the ternaries, +0.0 or -0.0 here) and NaN inputs, whose byte is 0 either way. */
+__device__ __forceinline__ float aces_med3(float x)
 {
-    if (through_half) f = half_round(f);
-    f = aces(f);                                                              /* :1366 */
-    const float est = pow01(f, 1.0f / 2.2f);                                  /* :1367; aces() clamps to [0, 1] */
-    uint32_t b = (uint32_t)(est * 255.0f);                                    /* :1368 (truncation) */
-    b = b > 255u ? 255u : b;
-    const float2 t = thr[b];
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;       /* src/vk_engine.cpp:1344-1351 */
+    return __builtin_amdgcn_fmed3f((x * (a * x + b)) / (x * (c * x + d) + e), 0.0f, 1.0f);
+}
+
+template <bool HALF>
+__device__ __forceinline__ uint32_t to_u8(const float2* thr, float f)
+{
+    if (HALF) f = half_round(f);
+    f = aces_med3(f);                                                         /* :1366 */
+    const float est = pow01(f, 1.0f / 2.2f);                                  /* :1367; f is in [0, 1], so is est */
+    uint32_t b = (uint32_t)(est * 255.0f);                                    /* :1368 (truncation); <= 255 */
+    const float2 t = thr[b & 255u];
     b -= f < t.x ? 1u : 0u;
     b += f >= t.y ? 1u : 0u;
     return b;
 }
-__device__ __forceinline__ uint32_t to_u16(float f, const int through_half)
+template <bool HALF>
+__device__ __forceinline__ uint32_t to_u16(float f)
 {
-    if (through_half) f = half_round(f);
-    f = f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f);                              /* :2068 */
+    if (HALF) f = half_round(f);
+    f = __builtin_amdgcn_fmed3f(f, 0.0f, 1.0f);                               /* :2068 (NaN -> 0 either way) */
     return (uint32_t)(f * 65535.0f);                                          /* :2069 */
 }
 
+/* Walks the quads (four consecutive pixels of an output row) q = first, first + stride, ... of a W x H frame: (y, x4) kept
+ * incrementally -- a 64-bit q / (W / 4) per trip was a fifth of the kernel's instructions. */
+struct QuadWalk {
+    uint32_t y, x, dy, dx, wq;
+    __device__ __forceinline__ QuadWalk(uint32_t first, uint32_t stride, uint32_t wq_) : wq(wq_)
+    {
+        y = first / wq; x = first - y * wq;
+        dy = stride / wq; dx = stride - dy * wq;
+    }
+    __device__ __forceinline__ void step() { x += dx; y += dy; if (x >= wq) { x -= wq; ++y; } }
+};
+
+template <bool HALF>
 __global__ void __launch_bounds__(kBlockThreads)
-export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8, int W, int H, int through_half, int quads_ok,
+export_rgb8_kernel(const float4* __restrict__ rgba, uint8_t* __restrict__ rgb8, int W, int H, int quads_ok,
                    const float2* __restrict__ thr_global)
 {
     __shared__ float2 thr[256];
     thr[threadIdx.x] = thr_global[threadIdx.x];                               /* kBlockThreads == 256 entries */
     __syncthreads();
-    const size_t n = (size_t)W * (size_t)H;
-    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = (uint32_t)W * (uint32_t)H;                             /* < 2^31 (fr_params_validate) */
+    const uint32_t stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
     if (quads_ok) {
-        const size_t quads = n >> 2, wq = (size_t)W >> 2;
+        const uint32_t quads = n >> 2;
         uint32_t* out = reinterpret_cast<uint32_t*>(rgb8);                    /* 12 bytes per quad: 4-byte aligned */
-        for (size_t q = first; q < quads; q += stride) {
-            const size_t y = q / wq, x = (q - y * wq) << 2;
-            const float4* src = rgba + (size_t)(H - 1 - (int)y) * W + x;       /* :1359 flip */
+        QuadWalk w(first, stride, (uint32_t)W >> 2);
+        for (uint32_t q = first; q < quads; q += stride, w.step()) {
+            const float4* src = rgba + (size_t)((uint32_t)H - 1u - w.y) * (uint32_t)W + (w.x << 2);   /* :1359 flip */
             const float4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
-            const uint32_t b[12] = {to_u8(thr, p0.x, through_half), to_u8(thr, p0.y, through_half), to_u8(thr, p0.z, through_half),
-                                    to_u8(thr, p1.x, through_half), to_u8(thr, p1.y, through_half), to_u8(thr, p1.z, through_half),
-                                    to_u8(thr, p2.x, through_half), to_u8(thr, p2.y, through_half), to_u8(thr, p2.z, through_half),
-                                    to_u8(thr, p3.x, through_half), to_u8(thr, p3.y, through_half), to_u8(thr, p3.z, through_half)};
-            uint32_t* o = out + q * 3;
+            const uint32_t b[12] = {to_u8<HALF>(thr, p0.x), to_u8<HALF>(thr, p0.y), to_u8<HALF>(thr, p0.z),
+                                    to_u8<HALF>(thr, p1.x), to_u8<HALF>(thr, p1.y), to_u8<HALF>(thr, p1.z),
+                                    to_u8<HALF>(thr, p2.x), to_u8<HALF>(thr, p2.y), to_u8<HALF>(thr, p2.z),
+                                    to_u8<HALF>(thr, p3.x), to_u8<HALF>(thr, p3.y), to_u8<HALF>(thr, p3.z)};
+            uint32_t* o = out + (size_t)q * 3;
             o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
             o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
             o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
         }
         return;
     }
-    for (size_t idx = first; idx < n; idx += stride) {
-        const int y = (int)(idx / (size_t)W), x = (int)(idx - (size_t)y * W);
-        const float4 v = rgba[(size_t)(H - 1 - y) * W + x];
-        rgb8[idx * 3 + 0] = (uint8_t)to_u8(thr, v.x, through_half);
-        rgb8[idx * 3 + 1] = (uint8_t)to_u8(thr, v.y, through_half);
-        rgb8[idx * 3 + 2] = (uint8_t)to_u8(thr, v.z, through_half);
+    QuadWalk w(first, stride, (uint32_t)W);                                   /* single pixels: the same walk, W per row */
+    for (uint32_t idx = first; idx < n; idx += stride, w.step()) {
+        const float4 v = rgba[(size_t)((uint32_t)H - 1u - w.y) * (uint32_t)W + w.x];
+        uint8_t* o = rgb8 + (size_t)idx * 3;
+        o[0] = (uint8_t)to_u8<HALF>(thr, v.x);
+        o[1] = (uint8_t)to_u8<HALF>(thr, v.y);
+        o[2] = (uint8_t)to_u8<HALF>(thr, v.z);
     }
 }
 
+template <bool HALF>
 __global__ void __launch_bounds__(kBlockThreads)
-export_rgb16_kernel(const float4* __restrict__ rgba, uint16_t* __restrict__ rgb16, int W, int H, int through_half, int quads_ok)
+export_rgb16_kernel(const float4* __restrict__ rgba, uint16_t* __restrict__ rgb16, int W, int H, int quads_ok)
 {
-    const size_t n = (size_t)W * (size_t)H;
-    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = (uint32_t)W * (uint32_t)H;
+    const uint32_t stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
     if (quads_ok) {
-        const size_t quads = n >> 2, wq = (size_t)W >> 2;
+        const uint32_t quads = n >> 2;
         uint2* out = reinterpret_cast<uint2*>(rgb16);                         /* 24 bytes per quad: 8-byte aligned */
-        for (size_t q = first; q < quads; q += stride) {
-            const size_t y = q / wq, x = (q - y * wq) << 2;
-            const float4* src = rgba + (size_t)(H - 1 - (int)y) * W + x;       /* :2058 flip */
+        QuadWalk w(first, stride, (uint32_t)W >> 2);
+        for (uint32_t q = first; q < quads; q += stride, w.step()) {
+            const float4* src = rgba + (size_t)((uint32_t)H - 1u - w.y) * (uint32_t)W + (w.x << 2);   /* :2058 flip */
             const float4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
-            const uint32_t h[12] = {to_u16(p0.x, through_half), to_u16(p0.y, through_half), to_u16(p0.z, through_half),
-                                    to_u16(p1.x, through_half), to_u16(p1.y, through_half), to_u16(p1.z, through_half),
-                                    to_u16(p2.x, through_half), to_u16(p2.y, through_half), to_u16(p2.z, through_half),
-                                    to_u16(p3.x, through_half), to_u16(p3.y, through_half), to_u16(p3.z, through_half)};
-            uint2* o = out + q * 3;
+            const uint32_t h[12] = {to_u16<HALF>(p0.x), to_u16<HALF>(p0.y), to_u16<HALF>(p0.z),
+                                    to_u16<HALF>(p1.x), to_u16<HALF>(p1.y), to_u16<HALF>(p1.z),
+                                    to_u16<HALF>(p2.x), to_u16<HALF>(p2.y), to_u16<HALF>(p2.z),
+                                    to_u16<HALF>(p3.x), to_u16<HALF>(p3.y), to_u16<HALF>(p3.z)};
+            uint2* o = out + (size_t)q * 3;
             o[0] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
             o[1] = make_uint2(h[4] | (h[5] << 16), h[6] | (h[7] << 16));
             o[2] = make_uint2(h[8] | (h[9] << 16), h[10] | (h[11] << 16));
         }
         return;
     }
-    for (size_t idx = first; idx < n; idx += stride) {
-        const int y = (int)(idx / (size_t)W), x = (int)(idx - (size_t)y * W);
-        const float4 v = rgba[(size_t)(H - 1 - y) * W + x];
-        rgb16[idx * 3 + 0] = (uint16_t)to_u16(v.x, through_half);
-        rgb16[idx * 3 + 1] = (uint16_t)to_u16(v.y, through_half);
-        rgb16[idx * 3 + 2] = (uint16_t)to_u16(v.z, through_half);
+    QuadWalk w(first, stride, (uint32_t)W);
+    for (uint32_t idx = first; idx < n; idx += stride, w.step()) {
+        const float4 v = rgba[(size_t)((uint32_t)H - 1u - w.y) * (uint32_t)W + w.x];
+        uint16_t* o = rgb16 + (size_t)idx * 3;
+        o[0] = (uint16_t)to_u16<HALF>(v.x);
+        o[1] = (uint16_t)to_u16<HALF>(v.y);
+        o[2] = (uint16_t)to_u16<HALF>(v.z);
     }
 }
 

@@ -37,6 +37,10 @@ extern "C" {
 
 int fr_ctx_set_tuning(fr_ctx* ctx, const char* name, int64_t value);
 
+/* RCCL leg of fr_node on ONE device (fr_node.cpp): plugin load, one-rank communicator, a grouped ncclSend / ncclRecv of
+ * `bytes` bytes to itself on a stream, compared on the host.  *rccl_version receives ncclGetVersion(). */
+int fr_node_rccl_selftest(int device, size_t bytes, int* rccl_version);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,12 +138,13 @@ class Renderer:
         return a.ctypes.data, "host"
 
     def _output(self, precision: Precision, rows: int, width: int, rgba, nu, it) -> _capi.fr_output:
+        # (also called with self = None by Node.render: uses nothing of the instance)
         npx = rows * width
         nu_dtype = "float64" if precision == Precision.F64 else "float32"   # Deep_Zoom callers pass Precision.F32
         kinds = set()
         o = _capi.fr_output()
         for name, x, dt, n in (("rgba", rgba, "float32", npx * 4), ("nu", nu, nu_dtype, npx), ("iter", it, "int32", npx)):
-            p, kind = self._ptr(x, dt, n, name)
+            p, kind = Renderer._ptr(x, dt, n, name)
             setattr(o, name, p)
             if kind:
                 kinds.add(kind)
@@ -260,6 +261,59 @@ class Renderer:
         else:
             _capi.check(self._lib.fr_export_rgb8(self._ctx, p_in, width, height, p_out, mem, int(through_half)))
         return out
+
+
+class Node:
+    """fr_node: one frame over the GPUs of a node behind the C ABI -- one process, one render context, stream and host
+    worker thread per device, parts rendered concurrently, the frame assembled on devices[root] by in-place peer stores
+    or by an RCCL gather (include/fractalrenderer_amd.h).  `devices` may repeat an ordinal (render lanes on one card)."""
+
+    def __init__(self, devices):
+        self._lib = _capi.lib()
+        devs = [int(d) for d in devices]
+        arr = (C.c_int * len(devs))(*devs)
+        h = C.c_void_p()
+        _capi.check(self._lib.fr_node_create(arr, len(devs), C.byref(h)))
+        self._node = h
+        self.devices = devs
+
+    def close(self) -> None:
+        if getattr(self, "_node", None):
+            self._lib.fr_node_destroy(self._node)
+            self._node = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_option(self, name: str, value: int) -> None:
+        _capi.check(self._lib.fr_node_set_option(self._node, name.encode(), int(value)))
+
+    def render(self, state: FractalState, width: int, height: int, *, root: int = 0,
+               fractal_type: FractalType = FractalType.Mandelbrot, precision: Precision = Precision.F64,
+               post_chain: bool = False, rgba=None, nu=None, iter=None, sync: bool = True) -> None:
+        """fr_node_render (sync=False: fr_node_render_async; call wait())."""
+        p = state.to_params(fractal_type, precision, post_chain)
+        out = Renderer._output(None, precision, height, width, rgba, nu, iter)
+        fn = self._lib.fr_node_render if sync else self._lib.fr_node_render_async
+        _capi.check(fn(self._node, C.byref(p), width, height, int(root), C.byref(out)))
+
+    def wait(self) -> None:
+        _capi.check(self._lib.fr_node_wait(self._node))
+
+    def last_gather(self) -> int:
+        return int(self._lib.fr_node_last_gather(self._node))
+
+    def last_kernel_ms(self, part: int) -> float:
+        return float(self._lib.fr_node_last_kernel_ms(self._node, int(part)))
 
 
 def export8_thresholds() -> np.ndarray:

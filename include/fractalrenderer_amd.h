@@ -144,6 +144,15 @@ typedef enum fr_memory {
                              scratch it owns and copies back (PCIe-inclusive path)          */
 } fr_memory;
 
+/* Where a part of a row-strip sharding (fr_shard) stores its rows. */
+typedef enum fr_layout {
+    FR_LAYOUT_PACKED = 0, /* the planes hold only this part's rows, packed densely in strip order (fr_shard_rows() rows) */
+    FR_LAYOUT_FRAME  = 1  /* the planes are WHOLE-FRAME planes (height rows) and the part stores its rows in place: the parts
+                             of a frame may then share one set of planes -- on one device, or on a peer device whose memory
+                             is mapped (hipDeviceEnablePeerAccess): the gather of a multi-GPU frame fused into the kernels'
+                             stores (fr_node_render).  FR_MEM_DEVICE only. */
+} fr_layout;
+
 /* Output planes of one render.  rgba is required unless nu or iter is given. */
 typedef struct fr_output {
     float*   rgba;     /* rows*W*4 f32, linear colour (or post-chained with FR_FLAG_POST_CHAIN) */
@@ -153,6 +162,7 @@ typedef struct fr_output {
     int32_t* iter;     /* rows*W index i of the escaping update (shaders/mandelbrot.comp:157-170),
                           max_iterations for interior.  NULL to skip                        */
     int32_t  memory;   /* fr_memory                                                         */
+    int32_t  layout;   /* fr_layout (0 = packed part rows; occupies what was padding before 1.0) */
 } fr_output;
 
 /* Row-strip sharding of one frame over the GPUs of a node: the frame's rows are cut
@@ -255,6 +265,54 @@ int fr_ctx_last_grid(fr_ctx* ctx);
 
 /* Number of compute units of the context's device (hipDeviceProp_t.multiProcessorCount). */
 int fr_ctx_compute_units(fr_ctx* ctx);
+
+/* Waits for everything this context has enqueued on its OWN stream (fr_render_shard_async with a NULL stream, the
+ * exports, fr_colorize_async with a NULL stream) and returns fr_ctx_check()'s verdict. */
+int fr_ctx_synchronize(fr_ctx* ctx);
+
+/* ---- one frame over the GPUs of a node (BASELINE.json north_star: "tiled across the 8 GPUs of one node as disjoint row
+ * bands with a final RCCL gather over xGMI") ---------------------------------------------------------------------------
+ * New design, no reference counterpart: the reference renders on the one GPU it picked (src/vk_engine.cpp:608).  What it
+ * replaces is the same RenderFrameCallback / dispatch surface as fr_render (src/animation_renderer.h:41-48,
+ * src/compute_effect_manager.h:435-468), for a caller that owns several devices: ONE process, one render context, one
+ * stream and one host worker thread per device.
+ *
+ * fr_node_create: devices[0..n-1] are HIP device ordinals (n <= 16).  They may repeat: n contexts on ONE device are n
+ *   concurrent render lanes of that device -- and how the band arithmetic and the in-place stores are tested on one card.
+ * fr_node_render: the frame's rows are cut into strips (fr_shard: strips of R rows dealt round-robin, part k on
+ *   devices[k]; "layout" = 1 makes them n contiguous bands), every part renders its rows concurrently, and the frame is
+ *   assembled in `out`, whose planes live on devices[root] (FR_MEM_DEVICE) or in host memory (FR_MEM_HOST: staged through
+ *   a frame buffer on devices[root]).  No collective on the compute path; the one exchange is the gather, by
+ *     FR_GATHER_PEER  the kernels of every part store straight into the root's planes (FR_LAYOUT_FRAME), mapped into the
+ *                     other devices' address spaces with hipDeviceEnablePeerAccess: the gather is fused into the stores,
+ *                     nothing is staged and nothing waits for a transfer phase (last sentence);
+ *     FR_GATHER_RCCL  every part renders into a buffer on its own device and ships its strips to the root with grouped
+ *                     ncclSend / ncclRecv (RCCL, point to point over xGMI's full mesh), received in place.  For the plain
+ *                     colourings the parts render and ship only the smooth-count plane (8 B/pixel instead of 16) and the
+ *                     root recolours the assembled frame (fr_colorize_async), bit-identically ("payload").  Needs
+ *                     distinct devices (one communicator rank per device); librccl is loaded at fr_node_create, through
+ *                     libfractalrenderer_amd_rccl.so, only for nodes that use it.
+ *   Planes are byte-identical to fr_render's, whatever n, root, layout and gather.
+ * fr_node_render_async + fr_node_wait: enqueue on all devices and return; wait for all of them and report.  Frames of a
+ *   sequence can be pipelined with rotating roots (frame f gathered to root f % n) so that all links carry traffic.
+ * fr_node_set_option: "gather" (fr_gather; 0 = automatic: RCCL for distinct devices, in-place stores otherwise),
+ *   "layout" (0 = interleaved strips, balanced within a frame; 1 = contiguous bands), "rows_per_strip" (0 = automatic:
+ *   32, a whole number of sub-tile rows), "payload" (0 = automatic: the smooth-count plane where fr_colorize_supported,
+ *   1 = always the planes asked for), and every fr_ctx_set_option name, applied to all contexts. */
+typedef struct fr_node fr_node;
+typedef enum fr_gather { FR_GATHER_AUTO = 0, FR_GATHER_PEER = 1, FR_GATHER_RCCL = 2 } fr_gather;
+
+int  fr_node_create(const int* devices, int n, fr_node** out);
+void fr_node_destroy(fr_node* node);
+int  fr_node_device_count(const fr_node* node);
+int  fr_node_set_option(fr_node* node, const char* name, int64_t value);
+int  fr_node_render(fr_node* node, const fr_params* p, uint32_t width, uint32_t height, int root, const fr_output* out);
+int  fr_node_render_async(fr_node* node, const fr_params* p, uint32_t width, uint32_t height, int root, const fr_output* out);
+int  fr_node_wait(fr_node* node);
+/* the gather the most recent render used (fr_gather, never AUTO), or < 0 before the first one */
+int  fr_node_last_gather(const fr_node* node);
+/* device time of part `part`'s kernels of the most recent render (fr_ctx_last_kernel_ms of its context) */
+float fr_node_last_kernel_ms(fr_node* node, int part);
 
 /* ---- recolour from the smooth-count plane (multi-GPU exchange payload) ------------------------
  * New design, no reference counterpart (the reference is single-GPU): for the plain colourings the

@@ -67,7 +67,7 @@ static int gpu_part(const char* png)
     fr_params p;
     fr_params_default(&p);
     p.max_iterations = 300;
-    fr_output out = {rgba, nu, it, FR_MEM_HOST};
+    fr_output out = {rgba, nu, it, FR_MEM_HOST, FR_LAYOUT_PACKED};
     CHECK(fr_render(ctx, &p, W, H, &out) == FR_OK);
     /* pixel (W/2, H/2) maps exactly to the centre (-0.5, 0): inside the main cardioid */
     CHECK(it[(H / 2) * W + W / 2] == 300 && nu[(H / 2) * W + W / 2] == 300.0);
@@ -94,7 +94,7 @@ static int gpu_part(const char* png)
     /* a part of a sharded frame equals the rows of the whole frame */
     fr_shard sh = {1u, 2u, 8u};
     static int32_t part[W * H];
-    fr_output po = {NULL, NULL, part, FR_MEM_HOST};
+    fr_output po = {NULL, NULL, part, FR_MEM_HOST, FR_LAYOUT_PACKED};
     CHECK(fr_render_shard(ctx, &p, W, H, &sh, &po) == FR_OK);
     const uint32_t rows = fr_shard_rows(&sh, H);
     for (uint32_t r = 0; r < rows; ++r)

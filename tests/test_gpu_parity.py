@@ -13,6 +13,8 @@ Bars:
     is 1e-4, and pixels next to black, where the final pow(c, 1/2.2) has unbounded slope, are compared before the
     gamma (1e-6).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -1241,6 +1243,89 @@ def test_plain_c_client_renders_through_the_abi(fr, tmp_path):
     exe = build_c_client(tmp_path)
     out = subprocess.run([exe, "gpu", str(tmp_path / "g.png")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip() == "gpu ok", out.stderr
+
+
+def test_plain_c_node_client_on_one_card(fr, tmp_path):
+    """tests/c_client/node_client.c: the C-ABI multi-GPU entry points from plain C.  `lanes`: n = 2, 4, 8 parts that are all
+    device 0 -- strips and bands, every root, in-place stores into one set of whole-frame planes -- bitwise against
+    fr_render; `rccl`: plugin load, communicator life cycle and a grouped ncclSend / ncclRecv pair on this card."""
+    import subprocess
+    from test_host import build_c_client
+    exe = build_c_client(tmp_path, "node_client.c")
+    out = subprocess.run([exe, "lanes"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip() == "lanes ok", out.stderr + out.stdout
+    out = subprocess.run([exe, "rccl"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("rccl ok"), out.stderr + out.stdout
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_node_render_equals_fr_render(fr, renderer, n):
+    """fr_node_render with n parts on this one card against fr_render, bitwise: device and host planes, strips / bands /
+    explicit strip heights (whole sub-tile rows: the lean tile kernel; 5 rows: the general one), every kind of kernel
+    behind the parts (two-pass fp64, Julia fp32, SSAA, effects, Deep_Zoom), rotating roots, async + wait."""
+    import torch
+    W, H = 328, 203
+    cases = [(dict(max_iterations=1024), fr.FractalType.Mandelbrot, fr.Precision.F64),
+             (dict(max_iterations=800, center_x=0.0, julia_c_real=-0.8, julia_c_imag=0.156), fr.FractalType.JuliaSet, fr.Precision.F32),
+             (dict(max_iterations=120, antialiasing_samples=2), fr.FractalType.Mandelbrot, fr.Precision.F64),
+             (dict(max_iterations=150, orbit_trap_enabled=True), fr.FractalType.Mandelbrot, fr.Precision.F32),
+             (dict(max_iterations=300, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-3, use_perturbation=True),
+              fr.FractalType.Deep_Zoom, fr.Precision.F32)]
+    with fr.Node([0] * n) as node:
+        for kw, ft, prec in cases:
+            st = fr.FractalState(**kw)
+            nu_dt = torch.float64 if prec == fr.Precision.F64 else torch.float32
+            want = (torch.empty((H, W, 4), dtype=torch.float32, device="cuda"), torch.empty((H, W), dtype=nu_dt, device="cuda"),
+                    torch.empty((H, W), dtype=torch.int32, device="cuda"))
+            renderer.render(st, W, H, fractal_type=ft, precision=prec, rgba=want[0], nu=want[1], iter=want[2])
+            for opts in (dict(), dict(layout=1), dict(rows_per_strip=8), dict(rows_per_strip=5), dict(rows_per_strip=64)):
+                for k in ("layout", "rows_per_strip"):
+                    node.set_option(k, opts.get(k, 0))
+                root = (len(opts) + n - 1) % n
+                got = tuple(torch.zeros_like(t) for t in want)
+                node.render(st, W, H, root=root, fractal_type=ft, precision=prec, rgba=got[0], nu=got[1], iter=got[2])
+                assert node.last_gather() == fr._capi.FR_GATHER_PEER
+                for a, b in zip(want, got):
+                    assert torch.equal(a, b), (kw, opts, n)
+            node.set_option("layout", 0); node.set_option("rows_per_strip", 0)
+            # host planes (staged through a frame on the root), colour only; async
+            rgba_h = np.zeros((H, W, 4), np.float32)
+            node.render(st, W, H, root=n - 1, fractal_type=ft, precision=prec, rgba=rgba_h, sync=False)
+            node.wait()
+            assert np.array_equal(rgba_h, want[0].cpu().numpy()), kw
+        with pytest.raises(fr.FractalRendererError):
+            node.render(fr.FractalState(), W, H, root=n, rgba=rgba_h)
+        if n > 1:
+            node.set_option("gather", fr._capi.FR_GATHER_RCCL)
+            with pytest.raises(fr.FractalRendererError) as e:
+                node.render(fr.FractalState(), W, H, rgba=rgba_h)
+            assert e.value.status == fr._capi.FR_ERR_UNSUPPORTED
+
+
+def test_whole_frame_layout_of_a_shard(fr, renderer):
+    """FR_LAYOUT_FRAME: a part stores its rows in place into whole-frame planes; rows of other parts stay untouched."""
+    import torch
+    W, H = 200, 120
+    st = fr.FractalState(max_iterations=900)
+    want = torch.empty((H, W), dtype=torch.float64, device="cuda")
+    renderer.render(st, W, H, nu=want)
+    for nparts, R in ((3, 8), (2, 5), (4, 16)):
+        frame = torch.full((H, W), -1.0, dtype=torch.float64, device="cuda")
+        for part in (0, nparts - 1):
+            sh = fr.Shard(part, nparts, R)
+            p = st.to_params(fr.FractalType.Mandelbrot, fr.Precision.F64)
+            out = fr._capi.fr_output(None, frame.data_ptr(), None, fr._capi.FR_MEM_DEVICE, fr._capi.FR_LAYOUT_FRAME)
+            shc = sh.to_c()
+            fr._capi.check(fr.lib().fr_render_shard(renderer._ctx, C.byref(p), W, H, C.byref(shc), C.byref(out)))
+            rows = torch.from_numpy(sh.global_rows(H)).cuda()
+            assert torch.equal(frame[rows], want[rows])
+        mine = np.concatenate([fr.Shard(k, nparts, R).global_rows(H) for k in (0, nparts - 1)]) if nparts > 1 else np.arange(H)
+        others = np.setdiff1d(np.arange(H), mine)
+        assert bool((frame[torch.from_numpy(others).cuda()] == -1.0).all())
+        host = np.empty((H, W), np.float64)
+        out = fr._capi.fr_output(None, host.ctypes.data, None, fr._capi.FR_MEM_HOST, fr._capi.FR_LAYOUT_FRAME)
+        p = st.to_params(fr.FractalType.Mandelbrot, fr.Precision.F64)
+        assert fr.lib().fr_render(renderer._ctx, C.byref(p), W, H, C.byref(out)) == fr._capi.FR_ERR_INVALID_ARG
 
 
 def test_distinct_contexts_render_concurrently_from_host_threads(fr):

@@ -467,13 +467,13 @@ def test_frame_naming_and_raw_pipe(fr):
         fr.write_raw_rgb24(-1, frame)
 
 
-def build_c_client(tmp_path):
-    """gcc-compiles tests/c_client/client.c against include/fractalrenderer_amd.h and the built library."""
+def build_c_client(tmp_path, source="client.c"):
+    """gcc-compiles tests/c_client/<source> against include/fractalrenderer_amd.h and the built library."""
     import subprocess
-    exe = str(tmp_path / "fr_client")
+    exe = str(tmp_path / ("fr_" + source[:-2]))
     libdir = os.path.join(ROOT, "fractalrenderer_amd")
     cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "c_client", "client.c"), "-o", exe,
+           os.path.join(ROOT, "tests", "c_client", source), "-o", exe,
            "-L" + libdir, "-lfractalrenderer_amd", "-lm", "-Wl,-rpath," + libdir]
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
@@ -487,6 +487,31 @@ def test_plain_c_client_host_entry_points(fr, golden, tmp_path):
     exe = build_c_client(tmp_path)
     out = subprocess.run([exe, "host", golden["franim"], str(tmp_path / "c.png")], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "host ok", out.stderr
+
+
+def test_node_entry_points_without_a_device(fr, tmp_path):
+    """The multi-GPU entry points are part of the C ABI: the plain-C node client compiles against the public header and
+    links; without a device fr_node_create fails loudly (no CPU path); the RCCL leg is its own library, which alone links
+    librccl and exports what fr_node.cpp binds."""
+    import subprocess
+    exe = build_c_client(tmp_path, "node_client.c")
+    assert os.path.exists(exe)
+    devs = (C.c_int * 2)(0, 0)
+    h = C.c_void_p()
+    st = fr.lib().fr_node_create(devs, 2, C.byref(h))
+    assert st == fr._capi.FR_ERR_NO_DEVICE and not h.value
+    assert fr.lib().fr_node_create(devs, 0, C.byref(h)) == fr._capi.FR_ERR_INVALID_ARG
+    libdir = os.path.join(ROOT, "fractalrenderer_amd")
+    plugin = os.path.join(libdir, "libfractalrenderer_amd_rccl.so")
+    assert os.path.exists(plugin)
+    syms = subprocess.run(["nm", "-D", "--defined-only", plugin], capture_output=True, text=True).stdout
+    for name in ("fr_rccl_init", "fr_rccl_destroy", "fr_rccl_group_start", "fr_rccl_group_end", "fr_rccl_send", "fr_rccl_recv",
+                 "fr_rccl_version"):
+        assert re.search(r"\bT %s\b" % name, syms), name
+    needed = subprocess.run(["objdump", "-p", plugin], capture_output=True, text=True).stdout
+    assert "librccl.so" in needed
+    main_needed = subprocess.run(["objdump", "-p", os.path.join(libdir, "libfractalrenderer_amd.so")], capture_output=True, text=True).stdout
+    assert "librccl" not in main_needed          # single-GPU callers never map the 570 MB library
 
 
 def test_export8_thresholds_against_an_exhaustive_scan(fr, oracle):

@@ -19,8 +19,8 @@ for line in out.stderr.splitlines():
     m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
     if m and cur is not None:
         cur[m.group(1).strip()] = int(m.group(2))
-want = sys.argv[1:] or ["tile_kernelIdLi0ELi3ELb0ELb0ELb0", "tile_kernelIfLi1ELi3ELb0ELb0ELb0", "pool_kernelIdLi0ELi3ELb1ELb0",
-                        "pool_kernelIdLi0ELi3ELb1ELb1", "pool_kernelIfLi1ELi3ELb1ELb0", "fused", "deep_zoom", "colorize_kernelIdLi0", "export"]
+want = sys.argv[1:] or ["tile_kernelIdLi0ELi3ELb0ELb0ELb0", "tile_kernelIfLi1ELi3ELb0ELb0ELb0", "pool_kernelIdLi0ELb0",
+                        "pool_kernelIdLi0ELb1", "pool_kernelIfLi1ELb0", "tile_lean_kernelIdLi0ELb0ELi2", "tile_lean_kernelIfLi1ELb0ELi2", "deep_zoom", "colorize_kernelIdLi0", "export"]
 print(f"{'kernel':84s} {'VGPR':>5s} {'SGPR':>5s} {'sSpill':>6s} {'vSpill':>6s} {'scratch':>7s} {'occ':>4s} {'LDS':>6s}")
 for name in sorted(usage):
     if any(w in name for w in want):
