@@ -151,6 +151,7 @@ INTERNAL_SIGNATURES = {
     "fr_ctx_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "fr_export8_thresholds": (None, [_P(C.c_float)]),          # fr_internal.h: byte thresholds of the 8-bit export
     "fr_node_rccl_selftest": (C.c_int, [C.c_int, C.c_size_t, _P(C.c_int)]),
+    "fr_ctx_last_pool_closing": (C.c_int, [C.c_void_p]),
 }
 PUBLIC_OPTIONS = ("periodicity", "staging", "shards", "tile_kernel", "diag_buffer", "diag_stride")
 TUNING_NAMES = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "stage_first", "pool_refill_at", "stream_run_max",
@@ -199,8 +200,16 @@ def lib() -> C.CDLL:
                 "or `make -C fractalrenderer_amd/csrc`. There is no Python/CPU fallback for the render path.")
         _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in list(SIGNATURES.items()) + list(INTERNAL_SIGNATURES.items()):
+        for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        for name, (res, args) in INTERNAL_SIGNATURES.items():
+            # internal entry points: required of the in-tree build, optional for an older build loaded through FR_LIB_PATH
+            # (A/B runs of two kernel versions in one GPU session)
+            if not hasattr(L, name) and os.environ.get("FR_LIB_PATH"):
+                continue
+            fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
         _lib = L

@@ -23,6 +23,8 @@ using namespace fr;
 static constexpr int kMaxStages = 2;            /* tile pass (+ lane-pool pass) */
 static constexpr size_t kStageWords = (size_t)2 * kMaxShards * kShardStrideWords;   /* one stage: its queue heads, then its stream counters */
 static constexpr size_t kCtrlWords = (size_t)kMaxStages * kStageWords;
+static constexpr size_t kFeedbackWord = kCtrlWords;            /* behind the stages: Feedback::dev_flag (kFeedbackShards words, 128 B apart) */
+static constexpr uint32_t kProbeEvery = 16;                     /* frames between two looks of a view that closed nothing */
 
 struct fr_ctx {
     int device;
@@ -70,6 +72,14 @@ struct fr_ctx {
     uint32_t* overflow_dev;     /* the same word as the kernels address it */
     bool render_on_user_stream; /* the most recent render was enqueued on a caller's stream: ev_end orders the context's
                                  * own stream (exports, colorize) behind it */
+    /* automatic cycle closing of the lane pool (pool_wants_cycle_closing) */
+    uint32_t render_seq;        /* renders enqueued on this context */
+    uint64_t probe_key;         /* what the context renders (fractal, precision, max_iter, geometry) */
+    int probe_mode;             /* 0 LOOK: every render's pool looks; 1 SKIP: none does, skip_left to go; 2 WAIT: one look is in
+                                 * flight (render probe_seq), nobody else looks until its verdict is back */
+    uint32_t probe_first;       /* LOOK: first render of the run of looks; WAIT: the one look */
+    uint32_t skip_left;
+    int last_pool_closing;      /* the most recent render's lane pool looked for cycles (1) / did not (0) / there was none (-1) */
     struct DivCheck { bool valid, julia, f64, ok; uint32_t W, H; };
     DivCheck div_cache[8];      /* exact_division_ok() results */
     uint32_t div_next;
@@ -119,7 +129,8 @@ extern "C" int fr_ctx_create(int device_ordinal, fr_ctx** out)
     if ((e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_begin)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_end)) != hipSuccess ||
-        (e2 = hipMalloc((void**)&c->d_ctrl, kCtrlWords * sizeof(uint32_t))) != hipSuccess ||
+        (e2 = hipMalloc((void**)&c->d_ctrl, (kCtrlWords + (size_t)(kFeedbackShards + 1) * kShardStrideWords) * sizeof(uint32_t))) != hipSuccess ||
+        (e2 = hipMemset(c->d_ctrl, 0, (kCtrlWords + (size_t)(kFeedbackShards + 1) * kShardStrideWords) * sizeof(uint32_t))) != hipSuccess ||
         (e2 = hipHostMalloc((void**)&c->overflow_host, 64, hipHostMallocMapped)) != hipSuccess ||
         (e2 = hipHostGetDevicePointer((void**)&c->overflow_dev, c->overflow_host, 0)) != hipSuccess ||
         (e2 = hipMalloc((void**)&c->log2_tab, sizeof(tab))) != hipSuccess ||
@@ -129,7 +140,8 @@ extern "C" int fr_ctx_create(int device_ordinal, fr_ctx** out)
         fr_ctx_destroy(c);                       /* releases whatever was created */
         return fr_set_error(FR_ERR_HIP, "context setup failed: %s", hipGetErrorString(e2));
     }
-    *c->overflow_host = 0u;
+    c->overflow_host[0] = 0u;
+    c->overflow_host[1] = 0u;                    /* the feedback word (Feedback::host_word) */
     *out = c;
     return FR_OK;
 }
@@ -352,11 +364,11 @@ static hipError_t launch_tile_lean(int np, dim3 grid, hipStream_t s, const Launc
 
 /* control block + coordinate tables of a lean render (prepare_kernel) */
 template <typename T, int FRACTAL>
-static hipError_t launch_prepare(hipStream_t s, const LaunchArgs& a, uint32_t* ctrl, uint32_t n_ctrl)
+static hipError_t launch_prepare(hipStream_t s, const LaunchArgs& a, uint32_t* ctrl, uint32_t n_ctrl, const Feedback& fb)
 {
     const uint32_t n = (uint32_t)(a.W + a.H) > n_ctrl ? (uint32_t)(a.W + a.H) : n_ctrl;
     const dim3 grid((n + kBlockThreads - 1) / kBlockThreads);
-    hipLaunchKernelGGL((prepare_kernel<T, FRACTAL == 0 ? 0 : 1>), grid, dim3(kBlockThreads), 0, s, a, ctrl, n_ctrl);
+    hipLaunchKernelGGL((prepare_kernel<T, FRACTAL == 0 ? 0 : 1>), grid, dim3(kBlockThreads), 0, s, a, ctrl, n_ctrl, fb);
     return hipGetLastError();
 }
 
@@ -415,11 +427,66 @@ static uint32_t period_window(const fr_ctx* c)
     return c->tune_periodicity < 0 ? 0u : (c->tune_periodicity == 0 ? 128u : (uint32_t)c->tune_periodicity);
 }
 
+/* what the first launch of a render forwards from the previous one (see Feedback) */
+static Feedback feedback_of(fr_ctx* c)
+{
+    Feedback fb;
+    fb.dev_flag = c->d_ctrl + kFeedbackWord;
+    fb.host_word = c->overflow_dev + 1;
+    fb.prev_seq = c->render_seq;                 /* the caller increments render_seq after its launches */
+    return fb;
+}
+
+/* Automatic cycle closing ("periodicity" = 0) of the lane pool.  Its PERIOD instantiation costs a frame in which nothing
+ * ever closes -- a Julia dust, the C5 view -- 7 % / 3.5 % (profiles/r03_periodicity_cost.txt: the comparisons were made
+ * all but free in round 3, the rest would not yield), and frames come in sequences of similar views.  So a context that
+ * has looked and closed NOTHING renders its next kProbeEvery - 1 frames of the same kind (fractal, precision, max_iter,
+ * geometry) with the plain instantiation, then looks again.  What the pool found travels back without a synchronisation
+ * (Feedback), so the verdict on frame n is known when frame n + 2 is planned -- or later, if the host runs ahead of the
+ * device: until then the pool keeps looking.  A view whose pools close cycles always looks.  Nothing a pixel depends on. */
+static bool pool_wants_cycle_closing(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t rows)
+{
+    if (c->tune_periodicity != 0) return c->tune_periodicity > 0;          /* explicit: on (any window) or off */
+    uint64_t key = 1469598103934665603ull;
+    const uint64_t parts[5] = {(uint64_t)p->fractal_type, (uint64_t)p->precision, (uint64_t)p->max_iterations, W, rows};
+    for (uint64_t v : parts) key = (key ^ v) * 1099511628211ull;
+    if (key != c->probe_key) { c->probe_key = key; c->probe_mode = 0; c->probe_first = 0; }
+    /* the verdict the device forwarded last: (render number << 1) | "closing cycles paid" (an eighth of the pool's records
+     * and more were retired by a closed cycle), of a render whose pool looked */
+    const uint32_t word = __atomic_load_n(c->overflow_host + 1, __ATOMIC_RELAXED);
+    const uint32_t seq = word >> 1;
+    const bool nothing_closed = (word & 1u) == 0u;
+    const uint32_t mine = c->render_seq + 1;                                /* this render's number */
+    switch (c->probe_mode) {
+    case 0:      /* LOOK: only renders whose pools looked are forwarded, and from probe_first on those are renders of this key:
+                  * any of their verdicts counts (a host that runs ahead of the device may never see the one of a particular
+                  * render) */
+        if (c->probe_first != 0 && seq >= c->probe_first && seq <= c->render_seq && nothing_closed) {
+            c->probe_mode = 1; c->skip_left = kProbeEvery - 2;
+            return false;
+        }
+        if (c->probe_first == 0) c->probe_first = mine;
+        return true;
+    case 1:      /* SKIP */
+        if (c->skip_left > 0) { --c->skip_left; return false; }
+        c->probe_mode = 2; c->probe_first = mine;                           /* the one look */
+        return true;
+    default:     /* WAIT: the host may be many frames ahead of the device; one look in flight is enough */
+        if (seq == c->probe_first) {
+            if (nothing_closed) { c->probe_mode = 1; c->skip_left = kProbeEvery - 2; return false; }
+            c->probe_mode = 0; c->probe_first = mine;                       /* the view closes cycles now: look again */
+            return true;
+        }
+        return false;
+    }
+}
+
 /* zero the queue heads and stream counters of the next render (a kernel, not a memset node: see clear_words_kernel) */
 static hipError_t clear_control_block(fr_ctx* c, hipStream_t stream, int nstages)
 {
     const uint32_t n = (uint32_t)((size_t)nstages * kStageWords);
-    hipLaunchKernelGGL(clear_words_kernel, dim3((n + 4 * kBlockThreads - 1) / (4 * kBlockThreads)), dim3(kBlockThreads), 0, stream, c->d_ctrl, n);
+    hipLaunchKernelGGL(clear_words_kernel, dim3((n + 4 * kBlockThreads - 1) / (4 * kBlockThreads)), dim3(kBlockThreads), 0, stream, c->d_ctrl, n,
+                       feedback_of(c));
     return hipGetLastError();
 }
 
@@ -503,6 +570,8 @@ static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t
     if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "deep-zoom kernel launch failed: %s", hipGetErrorString(e));
     FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
     c->have_timing = true;
+    ++c->render_seq;                             /* its first launch forwarded the previous render's verdict (Feedback) */
+    c->last_pool_closing = -1;
     return FR_OK;
 }
 
@@ -625,7 +694,7 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
  * must meet again to be averaged), the effects variants (accumulators along the whole orbit), short max_iter.  Returns
  * the number of passes; bounds[k] = upper iteration bound of pass k.  (Block stream passes with x4 budgets and a fused
  * one-launch schedule were built and measured slower everywhere: DESIGN.md section 7.) */
-static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t npx, int bounds[kMaxStages])
+static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t npx, bool pool_runs_everything, int bounds[kMaxStages])
 {
     const int max_iter = p->max_iterations;
     int nstage = 0;
@@ -634,6 +703,17 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t
      * 32 at max_iter 1024, 64 at 2048, 128-192 at 4096, flat at 16384) */
     int auto_first = ((max_iter / 28 + kFastBlock / 2) / kFastBlock) * kFastBlock;
     auto_first = auto_first < 32 ? 32 : (auto_first > 192 ? 192 : auto_first);
+    /* fp64 frames of 2^24 pixels and more whose lane pool runs every survivor to max_iter (cycle closing off, or skipped
+     * because it closed nothing lately): ~max_iter/11 within [96, 192].  Round 3's sweeps with the lean tile kernel
+     * (profiles/r03_b0_and_pool_tuning.txt): C2 (4096^2, 1024) 96 against 32: -1.8 %, C5 (8192^2, 4096) 192 against 144:
+     * -0.5 %; a 1080p frame at 1024 keeps 32 (96: +8 %), the fp32 Julia dust its 80 (96-128 within noise, 256: +8 %).
+     * A pool that closes cycles makes a survivor cheap, and the long tile pass only costs: C2 with cycle closing
+     * 0.517 ms at 32, 0.583 ms at 96. */
+    if (pool_runs_everything && p->precision == FR_PRECISION_F64 && npx >= ((size_t)1 << 24)) {
+        int big = ((max_iter / 11 + kFastBlock / 2) / kFastBlock) * kFastBlock;
+        big = big < 96 ? 96 : (big > 192 ? 192 : big);
+        if (big > auto_first) auto_first = big;
+    }
     const int first = c->tune_stage_first ? (int)c->tune_stage_first : auto_first;
     /* The second pass pays off where orbits are long: below max_iter ~768 (~384 on frames above 4K) ONE pass whose
      * waves stop at their home shard is faster -- 1080p at max_iter 256: 0.061 ms against 0.109 ms, the Seahorse view
@@ -730,8 +810,13 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.exact_div_ok = exact_division_ok(c, W, H, uv_map, f64) ? 1 : 0;
 
     int bounds[kMaxStages];
-    const int nstage = plan_stages(c, p, effects, (size_t)rows_local * W, bounds);
+    int nstage = plan_stages(c, p, effects, (size_t)rows_local * W, false, bounds);
     const bool staged = nstage > 1;
+    c->last_pool_closing = -1;
+    /* does this render's lane pool look for cycles?  (fr_ctx_reserve sizes for the pool that looks: the shorter tile pass
+     * leaves more survivors.) */
+    const bool pool_looks = staged && (reserve_only ? c->tune_periodicity >= 0 : pool_wants_cycle_closing(c, p, W, rows_local));
+    if (staged && !pool_looks) nstage = plan_stages(c, p, effects, (size_t)rows_local * W, true, bounds);   /* (still two passes) */
     /* survivor-stream writers move to the next region after every block: the regions come out equally
      * long with the same mix of blocks, so the reading pass is balanced with little stealing (measured,
      * profiles/r01_region_rotation.txt: C2 0.883 -> 0.831 ms, C3 0.598 -> 0.539 ms; regions by XCD = 1) */
@@ -794,7 +879,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
     if (lean) {
         hipError_t ep = by_variant(fractal, f64, [&](auto t, auto f) {
-            return launch_prepare<decltype(t), decltype(f)::value>(stream, a, c->d_ctrl, (uint32_t)((size_t)nstage * kStageWords)); });
+            return launch_prepare<decltype(t), decltype(f)::value>(stream, a, c->d_ctrl, (uint32_t)((size_t)nstage * kStageWords), feedback_of(c)); });
         if (ep != hipSuccess) return fr_set_error(FR_ERR_HIP, "prepare kernel launch failed: %s", hipGetErrorString(ep));
     } else {
         FR_HIP_TRY(clear_control_block(c, stream, nstage));
@@ -848,9 +933,11 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         /* a lane-pool wave holds its claimed blocks as a private reserve and only stalls for a dequeue
          * once per reserve, so claim little and never ahead: what a wave has reserved when the queue
          * runs dry is exactly the tail of the pass (measured: 1-3 block runs + one run prefetched left
-         * a 315 us drain on C2; a block of 64 interior records is ~60 us of work at 5 waves/SIMD) */
+         * a 315 us drain on C2; a block of 64 interior records is ~60 us of work at 5 waves/SIMD).
+         * ONE block per claim since round 3 (runs of 1-2 before): C2 -3.1 %, 1080p/1024 -0.9 %, C3 / C5 / C4 within
+         * +-1 % (profiles/r03_b0_and_pool_tuning.txt) */
         a.q.run_min = c->tune_stream_run_min ? c->tune_stream_run_min : 1u;
-        a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 2u;
+        a.q.run_max = c->tune_stream_run_max ? c->tune_stream_run_max : 1u;
         if (a.q.run_min > a.q.run_max) a.q.run_min = a.q.run_max;
         {
             uint32_t probes = c->tune_stream_probes ? c->tune_stream_probes : (rotate_regions ? 4u : 0u);
@@ -858,9 +945,13 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
             a.q.flags = probes << kQueueProbeShift;
         }
         a.diag = c->diag ? c->diag + c->diag_stride : nullptr;
-        a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : 24u;
+        /* finished lanes wait until this many are idle: 24 in fp32, 16 in fp64 (where a retire + refill round is cheaper
+         * relative to an update: C5 -1.5 %, 1080p/1024 -1.8 %, C2 / C4 unchanged; the fp32 dust +1.5 % with 16) */
+        a.pool_refill_at = c->tune_pool_refill ? c->tune_pool_refill : (f64 ? 16u : 24u);
         if (a.pool_refill_at > 64u) a.pool_refill_at = 64u;
-        a.period_window = period_window(c);
+        a.period_window = pool_looks ? period_window(c) : 0u;
+        c->last_pool_closing = a.period_window != 0u;
+        a.closed_flag = c->d_ctrl + kFeedbackWord;
         e = by_variant(fractal, f64, [&](auto t, auto f) {
             return launch_stream_pool<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
         if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "lane-pool kernel launch failed: %s", hipGetErrorString(e));
@@ -868,6 +959,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
     c->have_timing = true;
     c->last_stages = nstage;
+    ++c->render_seq;
     return FR_OK;
 }
 
@@ -939,6 +1031,9 @@ extern "C" int fr_ctx_synchronize(fr_ctx* c)
     FR_HIP_TRY(hipStreamSynchronize(c->stream));
     return check_overflow(c);
 }
+
+/* fr_tuning.h: 1 / 0 = the lane pool of the most recent render looked / did not look for cycles, -1 = it had no lane pool */
+extern "C" int fr_ctx_last_pool_closing(const fr_ctx* c) { return c ? c->last_pool_closing : -1; }
 
 extern "C" void* fr_ctx_stream_handle(fr_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int fr_ctx_device(const fr_ctx* c) { return c ? c->device : -1; }

@@ -151,6 +151,7 @@ struct LaunchArgs {
     void* xs; void* yds;
     double b2x4_d; float b2x4_f; /* 4 bailout^2 in the kernel's precision */
     uint64_t* diag;              /* optional: 4 words per wave (t_start, t_end, items, dequeues) */
+    uint32_t* closed_flag;       /* lane pool, PERIOD: set by a wave that closed a cycle (Feedback::dev_flag) */
     fr_palette_table pal;
 };
 
@@ -514,9 +515,55 @@ colorize_kernel(const LaunchArgs A, const T* __restrict__ nu_in, float4* __restr
  * Queue heads and stream counters of a render are zeroed by this kernel, not by hipMemsetAsync: a memset node captured
  * into a HIP graph did its work on the first replay only (ROCm 7.2: the second replay found the heads where the first
  * had left them and rendered nothing), and fr_render_shard_async is meant to be capturable. */
-__global__ void __launch_bounds__(kBlockThreads)
-clear_words_kernel(uint32_t* __restrict__ p, const uint32_t n)
+/* What the lane pool of a render tells the host about itself -- "did any wave close a cycle?" -- travels with the NEXT
+ * render's first launch: the pool's waves set a word in device memory, thread 0 of this launch forwards it (with the
+ * sequence number of the render it belongs to) to a host-mapped word and clears it.  No synchronisation, no extra launch;
+ * the host reads the word when it plans a later render (fr_device.hip, pool_wants_cycle_closing).  A hint only: nothing a
+ * pixel depends on. */
+constexpr int kFeedbackShards = 64;  /* the flag is 64 words, 128 B apart, a wave sets the one of its workgroup index: every wave
+                                      * of a C2 pool pass closes cycles, and 6 144 stores to ONE word at wave exit -- same-address
+                                      * stores are served ~15 ns apart, like the atomics -- held the end of the pass up by 80-120 us
+                                      * (1080p / 1024: 83 -> 164 us; profiles/r03_periodicity_cost.txt) */
+struct Feedback {
+    uint32_t* dev_flag;          /* kFeedbackShards pairs of words {samples retired by a closed cycle, records taken in},
+                                  * kShardStrideWords apart, added to by the waves of pool_kernel<.., PERIOD = true> when they
+                                  * leave; one more word behind them: "the render's lane pool LOOKED for cycles" (set by one
+                                  * wave of that kernel) -- only such a render has a verdict to forward */
+    uint32_t* host_word;         /* host-mapped: (sequence number of the render << 1) | "closing cycles paid" (an eighth of the
+                                  * pool's records and more were retired by a closed cycle), of the most recent render whose
+                                  * lane pool looked */
+    uint32_t prev_seq;           /* sequence number of the context's previous render */
+};
+__device__ __forceinline__ void forward_feedback(const Feedback& fb)
 {
+    if (fb.dev_flag && blockIdx.x == 0 && threadIdx.x < (uint32_t)kFeedbackShards) {          /* wave 0 of workgroup 0 */
+        uint32_t* w = fb.dev_flag + threadIdx.x * kShardStrideWords;
+        uint32_t closed = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t records = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            closed += (uint32_t)__shfl_xor((int)closed, off, 64);
+            records += (uint32_t)__shfl_xor((int)records, off, 64);
+        }
+        /* looking costs a frame in which nothing closes 4-7 %; a closed cycle saves most of its record's updates */
+        const bool any = closed != 0u && (uint64_t)closed * 8u >= (uint64_t)records;
+        if (threadIdx.x == 0) {
+            uint32_t* lw = fb.dev_flag + kFeedbackShards * kShardStrideWords;
+            const uint32_t looked = __hip_atomic_load(lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (looked != 0u) {
+                __hip_atomic_store(lw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(fb.host_word, (fb.prev_seq << 1) | (any ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlockThreads)
+clear_words_kernel(uint32_t* __restrict__ p, const uint32_t n, const Feedback fb)
+{
+    forward_feedback(fb);
     for (uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += gridDim.x * kBlockThreads) p[i] = 0u;
 }
 
@@ -1357,8 +1404,9 @@ tile_kernel(const LaunchArgs A)
  * T narrows center / zoom as the reference narrows them for its fp32 shaders (src/compute_effect_manager.h:85-90). */
 template <typename T, int MAP>
 __global__ void __launch_bounds__(kBlockThreads)
-prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n_ctrl)
+prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n_ctrl, const Feedback fb)
 {
+    forward_feedback(fb);
     const uint32_t stride = gridDim.x * kBlockThreads, first = blockIdx.x * kBlockThreads + threadIdx.x;
     for (uint32_t i = first; i < n_ctrl; i += stride) ctrl[i] = 0u;
     T* __restrict__ xs = reinterpret_cast<T*>(A.xs);
@@ -1885,6 +1933,10 @@ pool_kernel(const LaunchArgs A)
     bool have_running = false;
     uint32_t res_begin = 0, res_count = 0, res_shard = 0, res_next = 0;    /* reserve: run of 64-item groups, cursor in items */
     uint32_t life_avg = 0;                    /* PERIOD: smoothed lifetime (updates since its refill) of retired lanes */
+    /* PERIOD: what looking for cycles costs a wave that finds none (see `look`): stretches the wave stays ALERT (compares
+     * Re z and Im z, block by block) after it last saw a lane back at its snapshot; "this wave has closed a cycle" */
+    uint32_t alert = 0, n_closed = 0;
+    bool ever_closed = false;
     bool dry = false, fast = false;
 
     FR_STAMP_DECL
@@ -1893,7 +1945,7 @@ pool_kernel(const LaunchArgs A)
         FR_STAMP_BEGIN();
         const uint64_t finm = __builtin_amdgcn_ballot_w64(fin != 0u);
         if (finm != 0ull) {
-            if constexpr (PERIOD) {
+            if (PERIOD && ever_closed) {
                 /* lifetime of (the first of) the lanes retired now: its deadline was set to refill clock + remaining updates.
                  * (Read with the lane's number, in uniform control flow: a readfirstlane inside the divergent block below
                  * left the wave running on with the retiring lanes' EXEC mask -- the rest of the loop saw 17 lanes.) */
@@ -1998,7 +2050,7 @@ pool_kernel(const LaunchArgs A)
          * waiting for 24 keeps a fifth of the wave idle.  tau is taken from how long the lanes retired lately had lived
          * (64 lanes of lifetime L finish L / 64 apart). */
         uint32_t want = refill_at;
-        if constexpr (PERIOD) {
+        if (PERIOD && ever_closed) {       /* (a wave that has closed nothing retires lanes by escape and deadline only) */
             /* tau = (smoothed lifetime of the lanes retired lately) / 64 */
             const uint32_t tau = life_avg >> 6;
             want = tau >= 288u ? 4u : (tau >= 128u ? 6u : (tau >= 72u ? 8u : (tau >= 32u ? 12u : (tau >= 14u ? 18u : refill_at))));
@@ -2049,6 +2101,8 @@ pool_kernel(const LaunchArgs A)
                 const uint32_t nhit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
                 newly += nhit;
                 snap_closed += nhit;
+                n_closed += nhit;
+                ever_closed = true;
                 /* seen, but not at which block of the stretch: worth finding out only if the offset may be a long one
                  * (a short period closes within a few blocks whatever the stride) */
                 if (hit_off == 0u) learning = stride == 0u && wclock - snap_time >= 256u + 4u * (uint32_t)kFastBlock;
@@ -2066,7 +2120,9 @@ pool_kernel(const LaunchArgs A)
                 }
             }
             if ((int32_t)(wclock - next_snap) >= 0) {
-                refX = o.X; refYd = o.Yd;          /* parked lanes hold 0 == 0: masked by `running` above */
+                /* a slot that is not running gets a NaN snapshot: parked at z = 0 it would equal its own snapshot for ever,
+                 * and the cheap first look (Re z alone, see `look`) would fire in every block */
+                refX = running ? o.X : (T)__builtin_nanf(""); refYd = o.Yd;
                 if (snap_closed == 0u) {
                     /* a window that closed nothing is doubled (up to max_iter / 8); at the cap a learned stride is dropped */
                     if (snap_window < snap_cap) snap_window <<= 1;
@@ -2079,6 +2135,27 @@ pool_kernel(const LaunchArgs A)
                 min_hit = 0xFFFFFFFFu;
                 snap_time = wclock;
                 next_snap = wclock + snap_window;
+            }
+        };
+        /* WHAT looking costs where nothing closes (the C3 Julia dust, the C5 view: +7 % / +4.4 % in round 2; measured piece
+         * by piece in round 3, profiles/r03_periodicity_cost.txt: the per-block comparison 5 %, the lifetime bookkeeping of
+         * the refill threshold 1-3 %, everything else 2.5 %).  It is not the two compares, it is what hangs on them: a branch
+         * (or a select) on a mask the vector unit has only just produced, in every block.  So a wave is QUIET until it has a
+         * reason not to be: per block ONE v_cmp of Re z against the snapshot whose mask is ORed into a scalar pair -- nothing
+         * waits for it -- and one scalar test of that pair per stretch.  Re z back at its snapshot is the reason (for a
+         * sample not on a cycle it does not happen): the wave turns ALERT for the next 64 stretches -- every block compares
+         * Re z and Im z and the hit is taken at its block, as before -- and every lane seen renews that.  A quiet wave
+         * therefore sees a cycle one period (one lcm(16, p) for the long cycles of deep views) later than an alert one
+         * would, once; tested stretches do not look at all (an escape-dense neighbourhood: the wave returns to unchecked
+         * blocks as soon as 16 updates pass without an escape).  No sampling, no skipped stretches: a comparison that is
+         * skipped with a fixed phase misses a cycle of period 78 for ever (tried; the C4 view lost all its closures). */
+        bool saw = false;              /* some lane of the current stretch was seen back at its snapshot */
+        uint64_t hint = 0ull;          /* quiet wave: lanes whose Re z equalled the snapshot's at some block of the stretch */
+        auto look = [&](uint32_t& seen) {          /* alert */
+            if (__builtin_amdgcn_ballot_w64(o.X == refX) != 0ull) {
+                cold_path();
+                seen |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
+                saw = true;
             }
         };
         uint32_t clean = 0;            /* tested updates since the last escape */
@@ -2121,6 +2198,9 @@ pool_kernel(const LaunchArgs A)
                 if constexpr (PERIOD) { if (learning) reps = 1u; }
                 uint32_t len = reps * (uint32_t)kFastBlock;          /* updates of this stretch */
                 uint32_t seen = 0u;                                  /* PERIOD: lanes seen back at their snapshot */
+                saw = false;
+                hint = 0ull;
+                constexpr bool looking = PERIOD;
                 bool strided = false, exact = reps == 1u;            /* exact: a lane seen back was seen at the stretch's end */
                 if constexpr (PERIOD) strided = stride != 0u;
                 if (strided) {
@@ -2132,12 +2212,19 @@ pool_kernel(const LaunchArgs A)
                         for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
                     }
                     for (uint32_t r = len & 15u; r != 0u; --r) orbit_step<T, Form<FRACTAL>::abs_step>(o);
-                    if constexpr (PERIOD) seen = (o.X == refX && o.Yd == refYd) ? 1u : 0u;
-                } else {
+                    if (looking) look(seen);
+                } else if (looking && alert != 0u) {
                     for (uint32_t rep = 0; rep < reps; ++rep) {
 #pragma unroll
                         for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
-                        if constexpr (PERIOD) seen |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
+                        look(seen);
+                    }
+                } else {
+                    /* quiet (or no cycle closing at all): no branch inside the stretch */
+                    for (uint32_t rep = 0; rep < reps; ++rep) {
+#pragma unroll
+                        for (int k = 0; k < kFastBlock; ++k) orbit_step<T, Form<FRACTAL>::abs_step>(o);
+                        if (looking) hint |= __builtin_amdgcn_ballot_w64(o.X == refX);
                     }
                 }
                 const bool bad = !(orbit_r2x4(o) <= B2x4);
@@ -2169,7 +2256,11 @@ pool_kernel(const LaunchArgs A)
                 /* lanes at or past their deadline that are still running never escaped -> interior */
                 if ((int32_t)(wclock - next_deadline) >= 0) reach_deadline(true);
                 /* (a lane that escaped inside the stretch is finished: close_cycles only looks at running lanes) */
-                if constexpr (PERIOD) { cyc |= seen; close_cycles(exact ? wclock - snap_time : 0u); }
+                if constexpr (PERIOD) {
+                    alert = (saw || hint != 0ull) ? 64u : (alert != 0u ? alert - 1u : 0u);
+                    /* nothing seen and no snapshot due (the usual case where nothing closes): two scalar tests */
+                    if (saw || (int32_t)(wclock - next_snap) >= 0) { cyc |= seen; close_cycles(exact ? wclock - snap_time : 0u); }
+                }
                 continue;
             }
             /* tested stretch: up to the next deadline, at most one block.  The loop carries a countdown and
@@ -2205,22 +2296,21 @@ pool_kernel(const LaunchArgs A)
 #endif
             clean = escaped ? 0u : clean + k;
             if (wclock == next_deadline) reach_deadline(false);
-            if constexpr (PERIOD) {
-                /* escaped lanes are parked and finished: only running lanes count, and those were tested every update */
-                /* ... but not after a stretch in which something escaped: that is an escape-dense neighbourhood (a Julia
-                 * dust spends its whole pool pass in such stretches, and paid 8 % for looking); cycles are closed where
-                 * orbits run undisturbed */
-                if (!escaped) {
-                    cyc |= (o.X == refX && o.Yd == refYd) ? 1u : 0u;
-                    close_cycles(0u);
-                }
-            }
             /* back to unchecked blocks after a block's worth of updates without an escape */
             if (clean >= (uint32_t)kFastBlock) { fast = fast_ok; clean = 0; }
         }
 #ifdef FR_STAMP
         st_acc[1] = wclock;          /* pool: updates this wave has run (x 64 lanes = the lane-updates it paid for) */
 #endif
+    }
+    if constexpr (PERIOD) {
+        if (lane == 0 && A.closed_flag) {
+            uint32_t* w = A.closed_flag + (blockIdx.x & (uint32_t)(kFeedbackShards - 1)) * kShardStrideWords;
+            if (n_closed != 0u) atomicAdd(w, n_closed);
+            atomicAdd(w + 1, diag_items * 64u);                 /* records taken in (whole blocks claimed) */
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && A.closed_flag)        /* "this render's pool looked" */
+            __hip_atomic_store(A.closed_flag + kFeedbackShards * kShardStrideWords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (A.diag && lane == 0) {      /* as diag_write, with the dry time packed above the dequeue count */
         const uint32_t wave_id = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);

@@ -37,6 +37,11 @@ extern "C" {
 
 int fr_ctx_set_tuning(fr_ctx* ctx, const char* name, int64_t value);
 
+/* 1 / 0: the lane pool of the context's most recent render looked / did not look for cycles (automatic "periodicity":
+ * a context whose pools closed nothing skips the looking for a while, fr_device.hip pool_wants_cycle_closing); -1: that
+ * render had no lane pool */
+int fr_ctx_last_pool_closing(const fr_ctx* ctx);
+
 /* RCCL leg of fr_node on ONE device (fr_node.cpp): plugin load, one-rank communicator, a grouped ncclSend / ncclRecv of
  * `bytes` bytes to itself on a stream, compared on the host.  *rccl_version receives ncclGetVersion(). */
 int fr_node_rccl_selftest(int device, size_t bytes, int* rccl_version);

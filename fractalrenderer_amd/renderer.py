@@ -115,6 +115,10 @@ class Renderer:
     def last_kernel_ms(self) -> float:
         return float(self._lib.fr_ctx_last_kernel_ms(self._ctx))
 
+    def last_pool_closing(self) -> int:
+        """internal (fr_tuning.h): 1 / 0 = the lane pool of the most recent render looked / did not look for cycles, -1 = none"""
+        return int(self._lib.fr_ctx_last_pool_closing(self._ctx))
+
     # -- plane plumbing ------------------------------------------------------------------
     @staticmethod
     def _ptr(x, want_dtype: str, nelem: int, what: str):

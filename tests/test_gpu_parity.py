@@ -1245,6 +1245,42 @@ def test_plain_c_client_renders_through_the_abi(fr, tmp_path):
     assert out.returncode == 0 and out.stdout.strip() == "gpu ok", out.stderr
 
 
+def test_automatic_cycle_closing_stops_looking_where_nothing_closes(fr):
+    """"periodicity" = 0 (automatic): a context whose lane pools looked and closed nothing -- a Julia dust -- renders its
+    next frames of the same kind with the plain lane pool and looks again every 16th; one whose pools close cycles keeps
+    looking; an explicit setting is obeyed; and the planes never depend on any of it."""
+    import torch
+    W, H = 320, 200
+    dust = dict(state=fr.FractalState(max_iterations=2048, center_x=0.0, julia_c_real=-0.8, julia_c_imag=0.156),
+                fractal_type=fr.FractalType.JuliaSet, precision=fr.Precision.F32)
+    filled = dict(state=fr.FractalState(max_iterations=1024), fractal_type=fr.FractalType.Mandelbrot, precision=fr.Precision.F64)
+    with fr.Renderer(0) as r:
+        for case, expect_looks in ((dust, "few"), (filled, "all")):
+            nu_dt = torch.float64 if case["precision"] == fr.Precision.F64 else torch.float32
+            want = torch.empty((H, W), dtype=nu_dt, device="cuda")
+            r.set_option("periodicity", -1)
+            r.render(case["state"], W, H, fractal_type=case["fractal_type"], precision=case["precision"], nu=want)
+            assert r.last_stages() == 2 and r.last_pool_closing() == 0
+            r.set_option("periodicity", 1)
+            r.render(case["state"], W, H, fractal_type=case["fractal_type"], precision=case["precision"], nu=want.clone())
+            assert r.last_pool_closing() == 1
+            r.set_option("periodicity", 0)
+            looks = []
+            for _ in range(40):
+                got = torch.zeros_like(want)
+                r.render(case["state"], W, H, fractal_type=case["fractal_type"], precision=case["precision"], nu=got)
+                assert torch.equal(got, want)
+                looks.append(r.last_pool_closing())
+            if expect_looks == "all":
+                assert all(v == 1 for v in looks), looks
+            else:
+                assert looks[0] == 1 and 2 <= sum(looks) <= 12, looks          # the first frames, then one look in 16
+                assert sum(looks[:4]) >= 2 and 1 in looks[16:], looks
+        # a one-pass frame has no lane pool
+        r.render(fr.FractalState(max_iterations=100), W, H, nu=torch.empty((H, W), dtype=torch.float64, device="cuda"))
+        assert r.last_pool_closing() == -1
+
+
 def test_plain_c_node_client_on_one_card(fr, tmp_path):
     """tests/c_client/node_client.c: the C-ABI multi-GPU entry points from plain C.  `lanes`: n = 2, 4, 8 parts that are all
     device 0 -- strips and bands, every root, in-place stores into one set of whole-frame planes -- bitwise against
