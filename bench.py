@@ -31,10 +31,13 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                  on the launch stream over the timed region; traffic = PMC WRITE_SIZE+FETCH_SIZE per
                  launch from the committed rocprofv3 pass (profiles/), or null.
   roofline_valu  the bound that actually limits the kernel: fp64 VALU issue.
-                 achieved = 8 flop x executed iterations (counted exactly from the iter plane) / kernel
-                 time; peak = 39.3 T fp64 op/s (78.6 TFLOP/s FMA-counted / 2: the loop cannot contract).
-  cpu_baseline   the CPU oracle (oracle/fr_oracle.c, OpenMP, all host cores) timed on a bounded sample
-                 of the same frame, rank 0, N = 1 only.  kind "port": the reference has no CPU path.
+                 achieved / frac = 6 VALU instructions x executed iterations (counted exactly from the iter
+                 plane) / kernel time over peak = 39.3 T lane-instructions/s (78.6 TFLOP/s FMA-counted / 2:
+                 the loop cannot contract) -- the instruction-issue fraction, which cannot exceed 1;
+                 survey_8d = the same with SURVEY.md's 8 as-written flops per iteration (= frac x 8/6).
+  cpu_baseline   the CPU oracle (oracle/fr_oracle.c, OpenMP) timed on a bounded sample of the same frame, rank 0,
+                 N = 1 only: on 16 threads (the box's CPU share per GPU), on one thread and on every hardware thread
+                 the process can see.  kind "port": the reference has no CPU path.
 """
 from __future__ import annotations
 
@@ -146,6 +149,17 @@ def cpu_baseline(workload: dict) -> dict:
         O.render(p, W, H, y0=y0, y1=y0 + rows1, threads=1, planes=False)
         px1 += rows1 * W
     dt1 = time.perf_counter() - t1s
+    # ... and beside the 16-thread figure (the box's CPU share per GPU) the one on every hardware thread the process can see
+    # (one pass over the same bands; on a box whose cgroup caps the process at its share this cannot be faster, and says so)
+    all_threads = O.max_threads()
+    O.render(p, W, H, y0=0, y1=2, threads=all_threads, planes=False)
+    tas = time.perf_counter()
+    pxa = 0
+    for b in range(bands):
+        y0 = (H // bands) * b + (H // bands - band_rows) // 2
+        O.render(p, W, H, y0=y0, y1=y0 + band_rows, threads=all_threads, planes=False)
+        pxa += band_rows * W
+    dta = time.perf_counter() - tas
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -164,6 +178,8 @@ def cpu_baseline(workload: dict) -> dict:
     return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
             "single_thread": {"value": round(px1 / dt1 / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
                               "sample": f"1 pass over {bands} evenly spaced bands of {rows1} rows ({px1} pixels), {dt1:.1f} s"},
+            "all_hardware_threads": {"value": round(pxa / dta / 1e6, 3), "unit": "Mpixels/s", "cores": all_threads,
+                                     "sample": f"1 pass over the same bands ({pxa} pixels) with {all_threads} OpenMP threads, {dta:.1f} s"},
             "reference_orbit_iterations_per_s": round(orbit_rate, 0),
             "sample": f"{passes} passes over {bands} evenly spaced bands of {band_rows} rows ({px // passes} of {W*H} pixels) of the same frame, "
                       f"oracle/fr_oracle.c -O2 -ffp-contract=off, OpenMP schedule(dynamic,1), {dt:.1f} s",
@@ -694,19 +710,33 @@ def main() -> None:
             peak = FP64_VALU_PEAK_TOPS if prec == fr.Precision.F64 else FP32_VALU_PEAK_TOPS
             fpu = float(w.get("flops_per_update", 8))
             tops = fpu * executed / (kernel_ms * 1e-3) / 1e12
-            out["roofline_valu"] = {"bound": "valu_" + out["dtype"], "achieved": round(tops, 3), "peak": peak,
-                                    "unit": f"Tflop/s ({fpu:g} flop per executed iteration, no FMA credit)",
-                                    "frac": round(tops / peak, 4),
-                                    "issue_frac": round(tops * 6.0 / 8.0 / peak, 4) if fpu == 8 else None,
-                                    "issue_note": "the kernels issue 6 VALU instructions per update (two are FMAs by exact powers of "
-                                                  "two standing for two as-written operations each): frac prices the 8 as-written "
-                                                  "flops and can exceed 1, issue_frac prices the 6 instructions" if fpu == 8 else
-                                                  "as-written operations of one perturbed update, shaders/test_deep_zoom.comp:153-173: "
-                                                  "2 complex products with the reference point and delta (6 + 5), three additions of "
-                                                  "pairs (6), z = ref + delta (2), dot(z, z) (3), compare (1)",
-                                    "valu_busy_pmc": pmc_valu_busy(args.workload),
-                                    "executed_iterations": executed,
-                                    "mean_iterations_per_pixel": round(executed / (W * H), 2)}
+            if fpu == 8:
+                # PRIMARY: instruction issue.  An update is 6 VALU instructions (two of them FMAs by exact powers of two, each
+                # standing for two of the 8 as-written operations, bit for bit), so 6 x executed iterations over the non-FMA
+                # issue peak is a fraction that cannot exceed 1.  SURVEY.md section 8d's counting -- 8 as-written flops per
+                # iteration over the same peak -- is kept beside it as survey_8d; it flatters by 8/6 and can exceed 1.
+                tins = 6.0 * executed / (kernel_ms * 1e-3) / 1e12
+                out["roofline_valu"] = {"bound": "valu_" + out["dtype"], "achieved": round(tins, 3), "peak": peak,
+                                        "unit": "T lane-instructions/s (6 VALU instructions per executed iteration; peak = one "
+                                                "non-FMA instruction per lane and cycle)",
+                                        "frac": round(tins / peak, 4),
+                                        "survey_8d": {"achieved": round(tops, 3), "unit": "Tflop/s (8 as-written flops per executed "
+                                                      "iteration, no FMA credit)", "frac": round(tops / peak, 4),
+                                                      "note": "SURVEY.md section 8d's counting; = frac x 8/6, can exceed 1"},
+                                        "issue_frac": round(tins / peak, 4),
+                                        "valu_busy_pmc": pmc_valu_busy(args.workload),
+                                        "executed_iterations": executed,
+                                        "mean_iterations_per_pixel": round(executed / (W * H), 2)}
+            else:
+                out["roofline_valu"] = {"bound": "valu_" + out["dtype"], "achieved": round(tops, 3), "peak": peak,
+                                        "unit": f"Tflop/s ({fpu:g} flop per executed iteration, no FMA credit)",
+                                        "frac": round(tops / peak, 4),
+                                        "issue_note": "as-written operations of one perturbed update, shaders/test_deep_zoom.comp:153-173: "
+                                                      "2 complex products with the reference point and delta (6 + 5), three additions of "
+                                                      "pairs (6), z = ref + delta (2), dot(z, z) (3), compare (1)",
+                                        "valu_busy_pmc": pmc_valu_busy(args.workload),
+                                        "executed_iterations": executed,
+                                        "mean_iterations_per_pixel": round(executed / (W * H), 2)}
             if dt_cyc is not None:
                 out["periodicity"] = {"value": round(args.steps * W * H / dt_cyc / 1e6, 2), "unit": "Mpixels/s",
                                       "ms_per_step": round(dt_cyc / args.steps * 1e3, 4),
@@ -719,7 +749,7 @@ def main() -> None:
             if dt_pipe is not None:
                 out["pipelined"] = {"frames_in_flight": 2, "value": round(args.steps * W * H / dt_pipe / 1e6, 2),
                                     "unit": "Mpixels/s", "ms_per_step": round(dt_pipe / args.steps * 1e3, 4),
-                                    "valu_frac": round(8.0 * executed / (dt_pipe / args.steps) / 1e12 / peak, 4),
+                                    "valu_issue_frac": round(6.0 * executed / (dt_pipe / args.steps) / 1e12 / peak, 4),
                                     "note": "informational: two render contexts on two streams, frames alternating; "
                                             "the headline value above runs one frame at a time"}
             if not args.no_cpu_baseline:

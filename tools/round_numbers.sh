@@ -13,7 +13,7 @@ import json, sys
 for l in open(sys.argv[1]):
     d = json.loads(l); p = d.get("periodicity") or {}
     rv = d.get("roofline_valu") or {}
-    print(f"{d['metric']:28s} {d['ms_per_step']:9.4f} ms {d['value']:10.1f} Mpx/s  frac {rv.get('frac')}  issue {rv.get('issue_frac')}  iter/px {rv.get('mean_iterations_per_pixel')}  periodicity: {p.get('ms_per_step')} ms {p.get('value')}")
+    print(f"{d['metric']:28s} {d['ms_per_step']:9.4f} ms {d['value']:10.1f} Mpx/s  issue frac {rv.get('frac')}  8d frac {(rv.get('survey_8d') or {}).get('frac')}  iter/px {rv.get('mean_iterations_per_pixel')}  periodicity: {p.get('ms_per_step')} ms {p.get('value')}")
 P
 echo "== per-launch durations (tools/tile_time.py): defaults | general tile kernel, 8 shards"
 python3 tools/tile_time.py 15 c2 c2:tile_kernel=1,shards=8 c3 c3:tile_kernel=1,shards=8 c5 c5:tile_kernel=1,shards=8 far far:tile_kernel=1,shards=8 far:plane=iter far:plane=iter,tile_kernel=1,shards=8 uhd1k uhd1k:tile_kernel=1,shards=8 2>/dev/null
