@@ -149,17 +149,6 @@ def cpu_baseline(workload: dict) -> dict:
         O.render(p, W, H, y0=y0, y1=y0 + rows1, threads=1, planes=False)
         px1 += rows1 * W
     dt1 = time.perf_counter() - t1s
-    # ... and beside the 16-thread figure (the box's CPU share per GPU) the one on every hardware thread the process can see
-    # (one pass over the same bands; on a box whose cgroup caps the process at its share this cannot be faster, and says so)
-    all_threads = O.max_threads()
-    O.render(p, W, H, y0=0, y1=2, threads=all_threads, planes=False)
-    tas = time.perf_counter()
-    pxa = 0
-    for b in range(bands):
-        y0 = (H // bands) * b + (H // bands - band_rows) // 2
-        O.render(p, W, H, y0=y0, y1=y0 + band_rows, threads=all_threads, planes=False)
-        pxa += band_rows * W
-    dta = time.perf_counter() - tas
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -175,6 +164,18 @@ def cpu_baseline(workload: dict) -> dict:
     t1 = time.perf_counter()
     got = O.lib().fro_reference_orbit(-0.5, 0.0, n_orbit, buf.ctypes.data)
     orbit_rate = got / (time.perf_counter() - t1)
+    # (after the single-thread timings: 128 idle OpenMP workers spinning after their region slow a lone thread down)
+    # ... and beside the 16-thread figure (the box's CPU share per GPU) the one on every hardware thread the process can see
+    # (one pass over the same bands; on a box whose cgroup caps the process at its share this cannot be faster, and says so)
+    all_threads = O.max_threads()
+    O.render(p, W, H, y0=0, y1=2, threads=all_threads, planes=False)
+    tas = time.perf_counter()
+    pxa = 0
+    for b in range(bands):
+        y0 = (H // bands) * b + (H // bands - band_rows) // 2
+        O.render(p, W, H, y0=y0, y1=y0 + band_rows, threads=all_threads, planes=False)
+        pxa += band_rows * W
+    dta = time.perf_counter() - tas
     return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
             "single_thread": {"value": round(px1 / dt1 / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
                               "sample": f"1 pass over {bands} evenly spaced bands of {rows1} rows ({px1} pixels), {dt1:.1f} s"},
