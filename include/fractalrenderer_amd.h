@@ -238,7 +238,10 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                   being iterated to max_iter.  Exact, not a heuristic: the update is a deterministic function of (z, c),
  *                   so every plane stays byte-identical (tests/test_gpu_parity.py::test_periodicity_never_changes_a_pixel);
  *                   what changes is the number of iterations executed -- the reference's shaders iterate every interior
- *                   sample to max_iter (C2: 1.4x fewer, a filled Julia set 2.8x; a wave that sees no cycle stops looking).
+ *                   sample to max_iter (C2: 1.4x fewer, a filled Julia set 2.8x).  Automatic (0): a context whose lane pools
+ *                   retired less than an eighth of their records by closed cycles -- a Julia dust -- renders its next 14
+ *                   frames of the same kind without looking, then looks once more (no synchronisation: the verdict of a
+ *                   frame travels with the next frame's first launch); 1 / N: always look.
  *                   Not in the effects variants or Deep_Zoom.  bench.py's headline switches it OFF so that its roofline
  *                   is quoted on the reference's iteration count.
  *   "staging"       0 = automatic, 1 = single pass (every sample runs to max_iter in the tile kernel), 3 = tile pass for
