@@ -68,6 +68,7 @@ struct fr_ctx {
     uint32_t tune_shards;       /* 0 = automatic, 8 or 64: queue shards / stream regions of a render */
     uint32_t tune_regions;      /* 0 = automatic (= shards), 8 or 64: regions of the survivor streams */
     uint32_t tune_tile_pixels;  /* lean tile kernel: sub-tiles (pixels per lane) per trip, 0 = automatic (2), 1 or 2 */
+    uint32_t tune_pool_items_per_wg; /* lane pool grid: at most one workgroup per this many sub-tiles of the frame (0 = 32) */
     uint32_t* overflow_host;    /* pinned, device-mapped word: a survivor stream ran out of blocks (see StreamRef::overflow) */
     uint32_t* overflow_dev;     /* the same word as the kernels address it */
     bool render_on_user_stream; /* the most recent render was enqueued on a caller's stream: ev_end orders the context's
@@ -254,6 +255,9 @@ extern "C" int fr_ctx_set_tuning(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "tile_pixels")) {
         if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "tile_pixels must be 0 (automatic), 1 or 2");
         c->tune_tile_pixels = (uint32_t)value;
+    } else if (!strcmp(name, "pool_items_per_wg")) {
+        if (value < 0 || value > 4096) return fr_set_error(FR_ERR_INVALID_ARG, "pool_items_per_wg must be in [0,4096]");
+        c->tune_pool_items_per_wg = (uint32_t)value;
     } else if (!strcmp(name, "debug_region_blocks")) {
         c->debug_region_blocks = (uint32_t)value;     /* tests only (overflow reporting); 0 = the real capacity */
     } else {
@@ -845,7 +849,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     {   /* small frames: at most one wave per 8 sub-tiles of the frame (every survivor block holds 64 records, and
          * a frame rarely leaves more than a quarter of its pixels alive after the tile pass: ~2 blocks per wave;
          * 1080p at max_iter 1024: 0.144 ms with 6 workgroups per CU, 0.128 ms with the 4 this cap gives) */
-        const uint32_t cap = (tq.n_items + 31u) / 32u;
+        const uint32_t per_wg = c->tune_pool_items_per_wg ? c->tune_pool_items_per_wg : 32u;
+        const uint32_t cap = (tq.n_items + per_wg - 1u) / per_wg;
         if (sgrid > cap) sgrid = cap < 1u ? 1u : cap;
     }
     /* the survivor streams have as many regions as the tile queue has shards ("regions" overrides) */

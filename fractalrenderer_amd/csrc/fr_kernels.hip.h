@@ -50,6 +50,9 @@
 #include "fr_internal.h"
 
 #pragma clang fp contract(off)
+#ifndef FR_POOL64_WAVES
+#define FR_POOL64_WAVES 8
+#endif
 
 namespace fr {
 
@@ -1875,6 +1878,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
  * pool; it lost to tile pass + pool on every workload and left the product in round 3: DESIGN.md section 7.) */
 template <typename T, int FRACTAL, bool PERIOD = false>
 __global__ void __launch_bounds__(kBlockThreads)
+/* VGPRs are handed out in granules of 16 on gfx950 (measured: the 68-VGPR fp64 instantiation runs 6 workgroups per CU, not
+ * the 7 its count suggests; tools/timeline.py, live waves per tenth of a pass): 64 is what 8 waves per SIMD take.  The plain
+ * fp64 instantiation fits them (one SGPR spill, no scratch); the cycle-closing one does not (45 VGPRs to scratch) and stays at 6. */
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 && !PERIOD ? FR_POOL64_WAVES : 1)))
 pool_kernel(const LaunchArgs A)
 {
     constexpr int NF = RecFields<FRACTAL>::n;
@@ -2272,7 +2279,7 @@ pool_kernel(const LaunchArgs A)
             if (n > (uint32_t)kFastBlock) n = (uint32_t)kFastBlock;
             uint32_t k = 0;
             bool escaped = false;
-            do {
+            while (k < n) {
                 orbit_step<T, Form<FRACTAL>::abs_step>(o);
                 const T r2x4 = orbit_r2x4(o);
                 const bool e = r2x4 > B2x4;
@@ -2289,7 +2296,7 @@ pool_kernel(const LaunchArgs A)
                     escaped = true;
                     if (newly >= goal) n = k;        /* single-exit loop: goal reached -> this was the last update */
                 }
-            } while (k < n);
+            }
             wclock += k;
 #ifdef FR_STAMP_TESTED
             st_acc[0] += k;              /* diagnostic: updates this wave ran TESTED */

@@ -15,6 +15,7 @@
  *   "pool_refill_at"     lane pool: finished lanes wait until this many are idle (default 24)
  *   "stream_run_max", "stream_run_min"  run of survivor blocks one dequeue of the lane pool may claim
  *   "stream_workgroups_per_cu"          workgroups per compute unit of the lane-pool pass
+ *   "pool_items_per_wg"  lane-pool grid cap: at most one workgroup per this many sub-tiles of the frame (default 32)
  *   "probes", "stream_probes"  queue shards a wave tries before it exits, tile pass / lane-pool pass
  *                        (1..15; 0 = automatic: 1 (2 with 64 shards) for a staged or short-orbit tile pass, 4 for the lane
  *                        pool, all shards otherwise and on grids of fewer workgroups than shards)

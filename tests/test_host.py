@@ -561,7 +561,8 @@ def test_hot_kernels_keep_their_register_budget(fr):
     budget = {   # mangled name: (max VGPRs, min waves/SIMD, max SGPR spills)
         # lane pool: queue parameters, stream description and output planes are re-read from the kernel arguments where
         # they are used (kargs()), so nothing spills -- v_readlane / v_writelane are VALU issue slots
-        "_ZN2fr11pool_kernelIdLi0ELb0EEEvNS_10LaunchArgsE": (80, 6, 0),    # fp64 Mandelbrot lane pool (C2/C4/C5)
+        # (VGPRs come in granules of 16 on gfx950: 64 is what 8 waves per SIMD take; the kernel is held there by amdgpu_waves_per_eu)
+        "_ZN2fr11pool_kernelIdLi0ELb0EEEvNS_10LaunchArgsE": (64, 8, 2),    # fp64 Mandelbrot lane pool (C2/C4/C5)
         "_ZN2fr11pool_kernelIdLi0ELb1EEEvNS_10LaunchArgsE": (80, 6, 0),    # ... with cycle closing (the default)
         "_ZN2fr11pool_kernelIfLi1ELb0EEEvNS_10LaunchArgsE": (64, 6, 0),    # fp32 Julia lane pool (C3)
         "_ZN2fr11pool_kernelIfLi1ELb1EEEvNS_10LaunchArgsE": (64, 6, 0),    # ... with cycle closing (the default)
