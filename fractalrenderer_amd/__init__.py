@@ -8,7 +8,8 @@ from . import _capi
 from ._capi import FractalRendererError, lib
 from .state import (FractalState, FractalType, Precision, Preset, MANDELBROT_PRESETS,
                     SEAHORSE_DEEP, pack_push_constants)
-from .renderer import Renderer, Node, Shard, write_png, write_raw_rgb24, frame_path, export8_thresholds
+from .renderer import (Renderer, Node, Shard, write_png, write_raw_rgb24, frame_path, export8_thresholds, rccl_selftest,
+                       mapped_runtimes)
 from .animation import (AnimationSystem, AnimationRenderer, InterpolationType, Keyframe, DeepZoomPath, ZoomKeyframe)
 
 lib()  # no silent fallback: a missing/incomplete library is an import error
@@ -16,6 +17,6 @@ lib()  # no silent fallback: a missing/incomplete library is an import error
 __all__ = [
     "FractalRendererError", "lib", "FractalState", "FractalType", "Precision", "Preset",
     "MANDELBROT_PRESETS", "SEAHORSE_DEEP", "pack_push_constants", "Renderer", "Node", "Shard",
-    "write_png", "write_raw_rgb24", "frame_path", "export8_thresholds",
+    "write_png", "write_raw_rgb24", "frame_path", "export8_thresholds", "rccl_selftest", "mapped_runtimes",
     "AnimationSystem", "AnimationRenderer", "InterpolationType", "Keyframe", "DeepZoomPath", "ZoomKeyframe",
 ]

@@ -31,6 +31,7 @@ FR_LAYOUT_FRAME = 1
 FR_GATHER_AUTO = 0
 FR_GATHER_PEER = 1
 FR_GATHER_RCCL = 2
+FR_ROOT_ROTATE = -1
 
 FR_PRECISION_F32 = 0
 FR_PRECISION_F64 = 1
@@ -104,6 +105,9 @@ SIGNATURES = {
     "fr_node_render": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, C.c_int, _P(fr_output)]),
     "fr_node_render_async": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, C.c_int, _P(fr_output)]),
     "fr_node_wait": (C.c_int, [C.c_void_p]),
+    "fr_node_submit": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, C.c_int, _P(fr_output), _P(C.c_uint64)]),
+    "fr_node_wait_frame": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "fr_node_in_flight": (C.c_int, [C.c_void_p]),
     "fr_node_last_gather": (C.c_int, [C.c_void_p]),
     "fr_node_last_kernel_ms": (C.c_float, [C.c_void_p, C.c_int]),
     "fr_ctx_last_kernel_ms": (C.c_float, [C.c_void_p]),
@@ -152,6 +156,9 @@ INTERNAL_SIGNATURES = {
     "fr_export8_thresholds": (None, [_P(C.c_float)]),          # fr_internal.h: byte thresholds of the 8-bit export
     "fr_node_rccl_selftest": (C.c_int, [C.c_int, C.c_size_t, _P(C.c_int)]),
     "fr_ctx_last_pool_closing": (C.c_int, [C.c_void_p]),
+    "fr_node_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "fr_node_rccl_usable": (C.c_int, [C.c_void_p]),
+    "fr_node_mapped_runtimes": (C.c_int, [C.c_char_p, C.c_size_t]),
 }
 PUBLIC_OPTIONS = ("periodicity", "staging", "shards", "tile_kernel", "diag_buffer", "diag_stride")
 TUNING_NAMES = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "stage_first", "pool_refill_at", "stream_run_max",

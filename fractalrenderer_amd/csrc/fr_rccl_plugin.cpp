@@ -37,6 +37,15 @@ void fr_rccl_destroy(void** comms, int n)
         if (comms[k]) { (void)ncclCommDestroy((ncclComm_t)comms[k]); comms[k] = nullptr; }
 }
 
+/* ncclCommAbort: stops the operations a communicator still has enqueued or is blocked in (a receive whose send will never
+ * come) and frees it.  fr_node calls it for EVERY communicator of a node when a part of a gather failed after its peers
+ * had posted their side, so that no stream is left waiting for a transfer that cannot complete. */
+void fr_rccl_abort(void** comms, int n)
+{
+    for (int k = 0; k < n; ++k)
+        if (comms[k]) { (void)ncclCommAbort((ncclComm_t)comms[k]); comms[k] = nullptr; }
+}
+
 int fr_rccl_group_start(void) { return ncclGroupStart() == ncclSuccess ? 0 : -1; }
 
 int fr_rccl_group_end(char* err, size_t cap)

@@ -47,6 +47,23 @@ int fr_ctx_last_pool_closing(const fr_ctx* ctx);
  * `bytes` bytes to itself on a stream, compared on the host.  *rccl_version receives ncclGetVersion(). */
 int fr_node_rccl_selftest(int device, size_t bytes, int* rccl_version);
 
+/* fr_node: fault injection, the one-card RCCL loopback, and fr_ctx_set_tuning names for every render context of the node.
+ *   "fail_part_phase1"       k + 1: part k's next frame fails before its render is enqueued (one shot).  With the RCCL gather
+ *                            the two-phase barrier then keeps EVERY part out of its ncclGroupStart ... End.
+ *   "fail_part_before_send"  k + 1: part k's next RCCL frame fails after the barrier, its receives (if it is the root) posted
+ *                            and its sends not: the case that used to leave the root's stream waiting for ever.  The node
+ *                            answers with ncclCommAbort on every communicator.
+ *   "rccl_loopback"          1, nodes of ONE part: "gather" = 2 sends that part's strips through a one-rank communicator to
+ *                            itself (packed staging -> grouped ncclSend / ncclRecv -> in-place receives -> recolour of the
+ *                            smooth-count payload): the whole RCCL frame path on one card.
+ *   "rccl_timeout_ms"        how long a frame's wait lets an RCCL gather run before it aborts the communicators (30000) */
+int fr_node_set_tuning(fr_node* node, const char* name, int64_t value);
+/* 0 once the RCCL leg of the node was aborted */
+int fr_node_rccl_usable(const fr_node* node);
+/* the librccl / libamdhip64 / libfractalrenderer_amd files this process has mapped, one per line (from /proc/self/maps):
+ * which runtime the RCCL plugin bound to next to PyTorch's bundled copies */
+int fr_node_mapped_runtimes(char* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

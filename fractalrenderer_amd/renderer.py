@@ -301,6 +301,10 @@ class Node:
     def set_option(self, name: str, value: int) -> None:
         _capi.check(self._lib.fr_node_set_option(self._node, name.encode(), int(value)))
 
+    def set_tuning(self, name: str, value: int) -> None:
+        """fr_node_set_tuning (internal, csrc/fr_tuning.h): fault injection, the one-card RCCL loopback, context tuning."""
+        _capi.check(self._lib.fr_node_set_tuning(self._node, name.encode(), int(value)))
+
     def render(self, state: FractalState, width: int, height: int, *, root: int = 0,
                fractal_type: FractalType = FractalType.Mandelbrot, precision: Precision = Precision.F64,
                post_chain: bool = False, rgba=None, nu=None, iter=None, sync: bool = True) -> None:
@@ -310,14 +314,49 @@ class Node:
         fn = self._lib.fr_node_render if sync else self._lib.fr_node_render_async
         _capi.check(fn(self._node, C.byref(p), width, height, int(root), C.byref(out)))
 
+    def submit(self, state: FractalState, width: int, height: int, *, root: int = 0,
+               fractal_type: FractalType = FractalType.Mandelbrot, precision: Precision = Precision.F64,
+               post_chain: bool = False, rgba=None, nu=None, iter=None) -> int:
+        """fr_node_submit: hands one frame to the node and returns its ticket without waiting; up to "slots" frames are in
+        flight.  The planes must stay alive until wait_frame(ticket) / wait()."""
+        p = state.to_params(fractal_type, precision, post_chain)
+        out = Renderer._output(None, precision, height, width, rgba, nu, iter)
+        t = C.c_uint64(0)
+        _capi.check(self._lib.fr_node_submit(self._node, C.byref(p), width, height, int(root), C.byref(out), C.byref(t)))
+        return int(t.value)
+
+    def wait_frame(self, ticket: int) -> None:
+        _capi.check(self._lib.fr_node_wait_frame(self._node, int(ticket)))
+
     def wait(self) -> None:
         _capi.check(self._lib.fr_node_wait(self._node))
+
+    def in_flight(self) -> int:
+        return int(self._lib.fr_node_in_flight(self._node))
+
+    def rccl_usable(self) -> bool:
+        return bool(self._lib.fr_node_rccl_usable(self._node))
 
     def last_gather(self) -> int:
         return int(self._lib.fr_node_last_gather(self._node))
 
     def last_kernel_ms(self, part: int) -> float:
         return float(self._lib.fr_node_last_kernel_ms(self._node, int(part)))
+
+
+def rccl_selftest(device: int = 0, nbytes: int = 1 << 20) -> int:
+    """fr_node_rccl_selftest (internal): plugin load, one-rank communicator, a grouped ncclSend / ncclRecv pair on a stream,
+    compared on the host.  Returns ncclGetVersion()."""
+    v = C.c_int(0)
+    _capi.check(_capi.lib().fr_node_rccl_selftest(int(device), int(nbytes), C.byref(v)))
+    return int(v.value)
+
+
+def mapped_runtimes() -> list:
+    """fr_node_mapped_runtimes (internal): the librccl / libamdhip64 / libfractalrenderer_amd files this process has mapped."""
+    buf = C.create_string_buffer(1 << 16)
+    _capi.check(_capi.lib().fr_node_mapped_runtimes(buf, len(buf)))
+    return [ln for ln in buf.value.decode().split("\n") if ln]
 
 
 def export8_thresholds() -> np.ndarray:

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define FR_VERSION_MAJOR 1
-#define FR_VERSION_MINOR 0
+#define FR_VERSION_MINOR 1   /* 1.1: frames in flight on a node (fr_node_submit, fr_node_wait_frame, "slots", "lanes") */
 
 typedef enum fr_status {
     FR_OK               =  0,
@@ -273,48 +273,74 @@ int fr_ctx_compute_units(fr_ctx* ctx);
  * exports, fr_colorize_async with a NULL stream) and returns fr_ctx_check()'s verdict. */
 int fr_ctx_synchronize(fr_ctx* ctx);
 
-/* ---- one frame over the GPUs of a node (BASELINE.json north_star: "tiled across the 8 GPUs of one node as disjoint row
- * bands with a final RCCL gather over xGMI") ---------------------------------------------------------------------------
+/* ---- frames over the GPUs of a node (BASELINE.json north_star: "tiled across the 8 GPUs of one node as disjoint row
+ * bands with a final RCCL gather over xGMI") -----------------------------------------------------------------------------
  * New design, no reference counterpart: the reference renders on the one GPU it picked (src/vk_engine.cpp:608).  What it
  * replaces is the same RenderFrameCallback / dispatch surface as fr_render (src/animation_renderer.h:41-48,
- * src/compute_effect_manager.h:435-468), for a caller that owns several devices: ONE process, one render context, one
- * stream and one host worker thread per device.
+ * src/compute_effect_manager.h:435-468), for a caller that owns several devices and, like the reference's caller
+ * (AnimationRenderer::start_render, src/animation_renderer.cpp:75-127), renders a sequence of frames: ONE process, one
+ * host worker thread per device, up to 4 render contexts ("lanes") per device, a ring of frame slots.
  *
- * fr_node_create: devices[0..n-1] are HIP device ordinals (n <= 16).  They may repeat: n contexts on ONE device are n
- *   concurrent render lanes of that device -- and how the band arithmetic and the in-place stores are tested on one card.
- * fr_node_render: the frame's rows are cut into strips (fr_shard: strips of R rows dealt round-robin, part k on
- *   devices[k]; "layout" = 1 makes them n contiguous bands), every part renders its rows concurrently, and the frame is
- *   assembled in `out`, whose planes live on devices[root] (FR_MEM_DEVICE) or in host memory (FR_MEM_HOST: staged through
- *   a frame buffer on devices[root]).  No collective on the compute path; the one exchange is the gather, by
+ * fr_node_create: devices[0..n-1] are HIP device ordinals (n <= 16).  They may repeat: n parts on ONE device are n
+ *   concurrent renders on that device -- and how the band arithmetic and the in-place stores are tested on one card.
+ *   The caller's current device is left as it was, by this and every other fr_node_* call.
+ * A frame: its rows are cut into strips (fr_shard: strips of R rows dealt round-robin, part k on devices[k]; "layout" = 1
+ *   makes them n contiguous bands), every part renders its rows concurrently, and the frame is assembled in `out`, whose
+ *   planes live on devices[root] (FR_MEM_DEVICE) or in host memory (FR_MEM_HOST: staged through a frame buffer on
+ *   devices[root], copied back when the frame is waited for).  No collective on the compute path; the one exchange is the
+ *   gather, by
  *     FR_GATHER_PEER  the kernels of every part store straight into the root's planes (FR_LAYOUT_FRAME), mapped into the
  *                     other devices' address spaces with hipDeviceEnablePeerAccess: the gather is fused into the stores,
  *                     nothing is staged and nothing waits for a transfer phase (last sentence);
  *     FR_GATHER_RCCL  every part renders into a buffer on its own device and ships its strips to the root with grouped
- *                     ncclSend / ncclRecv (RCCL, point to point over xGMI's full mesh), received in place.  For the plain
- *                     colourings the parts render and ship only the smooth-count plane (8 B/pixel instead of 16) and the
- *                     root recolours the assembled frame (fr_colorize_async), bit-identically ("payload").  Needs
- *                     distinct devices (one communicator rank per device); librccl is loaded at fr_node_create, through
- *                     libfractalrenderer_amd_rccl.so, only for nodes that use it.
- *   Planes are byte-identical to fr_render's, whatever n, root, layout and gather.
- * fr_node_render_async + fr_node_wait: enqueue on all devices and return; wait for all of them and report.  Frames of a
- *   sequence can be pipelined with rotating roots (frame f gathered to root f % n) so that all links carry traffic.
- * fr_node_set_option: "gather" (fr_gather; 0 = automatic: RCCL for distinct devices, in-place stores otherwise),
+ *                     ncclSend / ncclRecv (RCCL, point to point over xGMI's full mesh) on a communication stream of its own,
+ *                     ordered behind its render by an event, received in place.  For the plain colourings the parts render
+ *                     and ship only the smooth-count plane (8 B/pixel instead of 16) and the root recolours the assembled
+ *                     frame (fr_colorize_async), bit-identically ("payload").  Needs distinct devices (one communicator
+ *                     rank per device); librccl is loaded, through libfractalrenderer_amd_rccl.so, by the first frame that
+ *                     uses it.  Fail-safe: every part enqueues its render and reports before ANY part posts a send or a
+ *                     receive, so the two sides always match; a failure after that point, or a gather that does not finish
+ *                     in 30 s, aborts every communicator (ncclCommAbort) instead of leaving a stream waiting, the frame
+ *                     reports the error, and the node carries on with FR_GATHER_PEER where the devices can map each other.
+ *   Planes are byte-identical to fr_render's, whatever n, root, layout, gather, slots and lanes.
+ * fr_node_render: one frame, synchronously (= fr_node_submit + fr_node_wait_frame).
+ * fr_node_submit: validates, takes a frame slot, hands the frame to the workers and returns its ticket (1, 2, ...) without
+ *   waiting for anything: up to "slots" frames are IN FLIGHT at once, frame t's parts running on lane t % "lanes" of every
+ *   device, so that frame t + 1's ramp-up fills frame t's drain (a 1/8 share of a frame rendered alone costs 1.8x its size).
+ *   A submit that finds its slot (ticket % slots) still holding an earlier frame first completes that frame; its verdict is
+ *   kept for its ticket (the last 64 are).  `root` is per frame: a caller rotates it (frame f to root f % n) so that every
+ *   link carries gather traffic; FR_ROOT_ROTATE does that for FR_MEM_HOST planes.  `out`'s planes must stay valid until the
+ *   frame has been waited for.  fr_node_render_async is fr_node_submit without the ticket.
+ * fr_node_wait_frame(ticket): waits for that frame alone (its parts' device work; FR_MEM_HOST: + the copy back), in any
+ *   order, and returns its verdict.  fr_node_wait: waits for every frame in flight, oldest first, and returns the first
+ *   failure nobody has been told about yet.
+ * One caller thread at a time drives a node (as one fr_ctx); distinct nodes are independent.
+ * fr_node_set_option (refused while frames are in flight): "gather" (fr_gather; 0 = automatic: in-place stores wherever
+ *   the devices can map each other -- the gather every one-card test compares bitwise --, RCCL where they cannot; an
+ *   explicit 2 whose plugin or communicators cannot be had falls back to 1 if possible: fr_node_last_gather tells),
  *   "layout" (0 = interleaved strips, balanced within a frame; 1 = contiguous bands), "rows_per_strip" (0 = automatic:
  *   32, a whole number of sub-tile rows), "payload" (0 = automatic: the smooth-count plane where fr_colorize_supported,
- *   1 = always the planes asked for), and every fr_ctx_set_option name, applied to all contexts. */
+ *   1 = always the planes asked for), "slots" (1..8 frames in flight, 0 = automatic: 2), "lanes" (1..4 render contexts
+ *   per part, created on first use, 0 = automatic: 2), and every fr_ctx_set_option name, applied to all contexts. */
 typedef struct fr_node fr_node;
 typedef enum fr_gather { FR_GATHER_AUTO = 0, FR_GATHER_PEER = 1, FR_GATHER_RCCL = 2 } fr_gather;
+#define FR_ROOT_ROTATE (-1)           /* fr_node_submit / fr_node_render: root = (ticket - 1) % n; FR_MEM_HOST planes */
 
 int  fr_node_create(const int* devices, int n, fr_node** out);
 void fr_node_destroy(fr_node* node);
 int  fr_node_device_count(const fr_node* node);
 int  fr_node_set_option(fr_node* node, const char* name, int64_t value);
 int  fr_node_render(fr_node* node, const fr_params* p, uint32_t width, uint32_t height, int root, const fr_output* out);
+int  fr_node_submit(fr_node* node, const fr_params* p, uint32_t width, uint32_t height, int root, const fr_output* out,
+                    uint64_t* ticket);
+int  fr_node_wait_frame(fr_node* node, uint64_t ticket);
 int  fr_node_render_async(fr_node* node, const fr_params* p, uint32_t width, uint32_t height, int root, const fr_output* out);
 int  fr_node_wait(fr_node* node);
-/* the gather the most recent render used (fr_gather, never AUTO), or < 0 before the first one */
+/* frames submitted and not waited for (or completed by a later submit) yet */
+int  fr_node_in_flight(const fr_node* node);
+/* the gather the most recently submitted frame uses (fr_gather, never AUTO), or < 0 before the first one */
 int  fr_node_last_gather(const fr_node* node);
-/* device time of part `part`'s kernels of the most recent render (fr_ctx_last_kernel_ms of its context) */
+/* device time of part `part`'s kernels of the most recently submitted frame (fr_ctx_last_kernel_ms of its context) */
 float fr_node_last_kernel_ms(fr_node* node, int part);
 
 /* ---- recolour from the smooth-count plane (multi-GPU exchange payload) ------------------------

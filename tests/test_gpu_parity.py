@@ -14,6 +14,7 @@ Bars:
     gamma (1e-6).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1292,6 +1293,91 @@ def test_plain_c_node_client_on_one_card(fr, tmp_path):
     assert out.returncode == 0 and out.stdout.strip() == "lanes ok", out.stderr + out.stdout
     out = subprocess.run([exe, "rccl"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("rccl ok"), out.stderr + out.stdout
+
+
+def test_plain_c_node_client_frames_in_flight(fr, tmp_path):
+    """`seq`: a 16-frame sequence on devices = {0} and {0,0,0,0} with 1..8 frame slots and 1..4 render lanes, rotating roots,
+    tickets waited for in a scrambled order, every frame bitwise against fr_render; a node destroyed with frames in flight."""
+    import subprocess
+    from test_host import build_c_client
+    exe = build_c_client(tmp_path, "node_client.c")
+    out = subprocess.run([exe, "seq"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip() == "seq ok", out.stderr + out.stdout
+
+
+def test_plain_c_node_client_gather_failure_paths(fr, tmp_path):
+    """`failsafe`: a part that fails before its render (reported under its frame's ticket, the node stays usable); a whole
+    frame through the RCCL calls of a one-rank communicator ("rccl_loopback": packed staging, grouped send / recv on the comm
+    stream, in-place receives, the smooth-count payload recoloured), two frames in flight; a part that fails between the
+    two-phase barrier and its sends: the communicators are aborted, the wait returns the error within its bound and the
+    node carries on with the in-place gather."""
+    import subprocess
+    from test_host import build_c_client
+    exe = build_c_client(tmp_path, "node_client.c")
+    out = subprocess.run([exe, "failsafe"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("failsafe ok"), out.stderr + out.stdout      # (RCCL prints a banner)
+
+
+def test_rccl_plugin_next_to_torch(fr):
+    """The RCCL leg of fr_node inside a process that holds PyTorch's bundled HIP runtime and RCCL (this one: torch is
+    imported and its CUDA context is up): the plugin loads, a one-rank communicator carries a grouped send / recv pair, and
+    a whole frame goes through the loopback gather, bitwise equal to fr_render -- with ONE libamdhip64 mapped."""
+    import torch
+    assert torch.cuda.is_available()
+    torch.zeros(4, device="cuda").sum().item()                      # torch's runtime is initialised before the plugin loads
+    assert fr.rccl_selftest(0, 1 << 20) > 0
+    W, H = 264, 136
+    st = fr.FractalState(max_iterations=1024)
+    want = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    with fr.Renderer(0) as r:
+        r.render(st, W, H, rgba=want)
+    with fr.Node([0]) as node:
+        node.set_tuning("rccl_loopback", 1)
+        node.set_option("gather", fr._capi.FR_GATHER_RCCL)
+        got = torch.zeros_like(want)
+        torch.cuda.synchronize()                                    # the fill runs on torch's stream
+        node.render(st, W, H, rgba=got)
+        assert node.last_gather() == fr._capi.FR_GATHER_RCCL and node.rccl_usable()
+        assert torch.equal(got, want)
+    maps = fr.mapped_runtimes()
+    print("mapped runtimes:", maps)
+    hips = {os.path.realpath(m) for m in maps if "libamdhip64" in m}
+    assert len(hips) == 1, maps
+    assert any("librccl" in m for m in maps), maps
+
+
+@pytest.mark.parametrize("n,slots,lanes", [(1, 2, 2), (4, 3, 2), (8, 8, 4)])
+def test_node_frames_in_flight_device_planes(fr, renderer, n, slots, lanes):
+    """fr_node_submit / fr_node_wait_frame with device planes: 12 different frames, up to `slots` in flight on `lanes` render
+    contexts per part, each into its own planes on the card, waited for newest first; bitwise against fr_render."""
+    import torch
+    W, H = 328, 203
+    frames = []
+    for f in range(12):
+        if f % 3 == 2:
+            frames.append((fr.FractalState(max_iterations=900, center_x=0.0, zoom=3.0 - 0.1 * f, julia_c_real=-0.8, julia_c_imag=0.156),
+                           fr.FractalType.JuliaSet, fr.Precision.F32))
+        else:
+            frames.append((fr.FractalState(max_iterations=1024 if f % 3 else 200, zoom=3.0 - 0.15 * f), fr.FractalType.Mandelbrot, fr.Precision.F64))
+    want = []
+    for st, ft, prec in frames:
+        nu_dt = torch.float64 if prec == fr.Precision.F64 else torch.float32
+        w = (torch.empty((H, W, 4), dtype=torch.float32, device="cuda"), torch.empty((H, W), dtype=nu_dt, device="cuda"))
+        renderer.render(st, W, H, fractal_type=ft, precision=prec, rgba=w[0], nu=w[1])
+        want.append(w)
+    with fr.Node([0] * n) as node:
+        node.set_option("slots", slots); node.set_option("lanes", lanes)
+        got = [tuple(torch.zeros_like(t) for t in w) for w in want]
+        torch.cuda.synchronize()                                    # the fills run on torch's stream
+        tickets = [node.submit(st, W, H, root=f % n, fractal_type=ft, precision=prec, rgba=got[f][0], nu=got[f][1])
+                   for f, (st, ft, prec) in enumerate(frames)]
+        assert tickets == list(range(tickets[0], tickets[0] + 12)) and 1 <= node.in_flight() <= slots
+        for f in reversed(range(12)):
+            node.wait_frame(tickets[f])
+            assert torch.equal(got[f][0], want[f][0]) and torch.equal(got[f][1], want[f][1]), f
+        assert node.in_flight() == 0
+        with pytest.raises(fr.FractalRendererError):
+            node.wait_frame(tickets[-1] + 1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 8])

@@ -33,7 +33,7 @@ def test_struct_layout_matches_header(fr):
     assert C.sizeof(fr._capi.fr_output) == 32 and C.sizeof(fr._capi.fr_shard) == 12
     major, minor = C.c_int(), C.c_int()
     fr.lib().fr_version(C.byref(major), C.byref(minor))
-    assert (major.value, minor.value) == (1, 0)
+    assert (major.value, minor.value) == (1, 1)       # 1.1: frames in flight on a node
 
 
 def test_no_device_fails_loudly(fr):
@@ -506,7 +506,7 @@ def test_node_entry_points_without_a_device(fr, tmp_path):
     assert os.path.exists(plugin)
     syms = subprocess.run(["nm", "-D", "--defined-only", plugin], capture_output=True, text=True).stdout
     for name in ("fr_rccl_init", "fr_rccl_destroy", "fr_rccl_group_start", "fr_rccl_group_end", "fr_rccl_send", "fr_rccl_recv",
-                 "fr_rccl_version"):
+                 "fr_rccl_version", "fr_rccl_abort"):
         assert re.search(r"\bT %s\b" % name, syms), name
     needed = subprocess.run(["objdump", "-p", plugin], capture_output=True, text=True).stdout
     assert "librccl.so" in needed
