@@ -25,6 +25,16 @@ case at N > 1: ONE frame tiled over the N GPUs as row strips with a final gather
 send/recv into the root, double-buffered so that gather(n) overlaps render(n+1)); at N = 1 both modes are the same
 whole-frame render.
 
+--host node: the C-ABI multi-GPU host instead of torch.distributed -- ONE process, ctypes -> fr_node over devices 0..N-1
+(one worker thread per device, frame slots, render lanes; fractalrenderer_amd/csrc/fr_node.cpp), from a bare shell:
+`python bench.py --gpus N --host node`.  Same JSON contract; value = --mode sequence (frames in flight, rotating roots) or
+--mode frame (one frame at a time, gathered to device 0) with the automatic gather, and a "node" object with every
+(gather, mode) pair that the box allows, each verified bitwise against fr_render.  --node-parts P cuts every frame into P
+parts per device (one-card rehearsals of the band arithmetic: --gpus 1 --node-parts 4 = devices {0,0,0,0}).
+Under the driver's torch.distributed.run command (WORLD_SIZE set, N > 1) the torch path stays the headline and rank 0 adds
+an informational "fr_node" object, measured in-process after the timed region while the other ranks wait at a host-side
+(gloo) barrier; FR_BENCH_NODE_LEG=0 switches that leg off.
+
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline       the metric's own roofline ("achieved HBM GB/s vs peak"): algorithmic bytes
                  16 B/pixel (RGBA f32, write-once) / average kernel time measured with HIP events
@@ -220,6 +230,13 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="sequence", choices=["sequence", "frame"],
                     help="N > 1: 'sequence' = K frames in rotating-root groups (FrameExchange); 'frame' = the north-star's "
                          "literal case, every frame tiled over the N GPUs as row strips and gathered to rank 0 (StripGather)")
+    ap.add_argument("--host", default="torch", choices=["torch", "node"],
+                    help="'torch' = one process per GPU, torch.distributed (the driver's command); 'node' = ONE process driving "
+                         "all N GPUs through the C ABI's fr_node (bare shell only)")
+    ap.add_argument("--node-parts", type=int, default=1, help="--host node: parts per device (each device ordinal listed this often)")
+    ap.add_argument("--node-slots", type=int, default=0, help="--host node: frames in flight (0: 2, or N at N > 2)")
+    ap.add_argument("--node-lanes", type=int, default=0, help="--host node: render contexts per part (0: 2)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "peer", "rccl"], help="--host node: the gather of the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelined", action="store_true",
                     help="N = 1: after the timed region, also time the same K steps with two frames in flight "
@@ -424,11 +441,155 @@ def kernel_workload(args, w) -> None:
     r.close()
 
 
+
+def node_measure(fr, torch, w, devices, steps, warmup, mode, gather, slots, lanes, options="", loopback=False) -> dict:
+    """K frames of workload `w` through fr_node over `devices` (ordinals, may repeat), device planes on each frame's root.
+    mode "sequence": up to `slots` frames in flight on `lanes` render contexts per part, frame f gathered to root f % n;
+    mode "frame": one frame at a time, every frame gathered to part 0.  Wall time between device-wide synchronisations;
+    afterwards one frame per root is compared bitwise with fr_render on that root's device."""
+    W, H = w["W"], w["H"]
+    state = fr.FractalState(**w["state"])
+    ftype, prec = fr.FractalType[w["fractal"]], fr.Precision[w["precision"]]
+    n = len(devices)
+    g = {"auto": fr._capi.FR_GATHER_AUTO, "peer": fr._capi.FR_GATHER_PEER, "rccl": fr._capi.FR_GATHER_RCCL}[gather]
+    node = fr.Node(devices)
+    try:
+        node.set_option("periodicity", -1)                     # the reference's iteration count, as the headline
+        for kv in filter(None, options.split(",")):
+            k, v = kv.split("=")
+            node.set_option(k.strip(), int(v, 0))
+        node.set_option("slots", slots if mode == "sequence" else 1)
+        node.set_option("lanes", lanes if mode == "sequence" else 1)
+        if loopback:
+            node.set_tuning("rccl_loopback", 1)
+        node.set_tuning("rccl_timeout_ms", 10000)
+        node.set_option("gather", g)
+        nplanes = n * ((slots + n - 1) // n) if mode == "sequence" else 1
+        planes = [torch.empty((H, W, 4), dtype=torch.float32, device=torch.device("cuda", devices[i % n])) for i in range(nplanes)]
+
+        def sync_all():
+            for d in sorted(set(devices)):
+                torch.cuda.synchronize(d)
+
+        def run(count):
+            if mode == "frame":
+                for _ in range(count):
+                    node.render(state, W, H, root=0, fractal_type=ftype, precision=prec, rgba=planes[0])
+            else:
+                for f in range(count):
+                    node.submit(state, W, H, root=f % n, fractal_type=ftype, precision=prec, rgba=planes[f % nplanes])
+                node.wait()
+
+        run(max(warmup, nplanes))
+        sync_all()
+        t0 = time.perf_counter()
+        run(steps)
+        sync_all()
+        dt = time.perf_counter() - t0
+        used = node.last_gather()
+        part_ms = [round(node.last_kernel_ms(k), 4) for k in range(n)]
+        # verification, outside the timed region: the frame on every root against fr_render there
+        ok = True
+        roots = range(n) if mode == "sequence" else [0]
+        for root in roots:
+            dev = torch.device("cuda", devices[root])
+            got = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+            want = torch.empty_like(got)
+            torch.cuda.synchronize(dev)
+            node.render(state, W, H, root=root, fractal_type=ftype, precision=prec, rgba=got)
+            with fr.Renderer(devices[root]) as rr:
+                rr.set_option("periodicity", -1)
+                rr.render(state, W, H, fractal_type=ftype, precision=prec, rgba=want)
+            ok = ok and bool(torch.equal(got, want))
+            del got, want
+            if len(set(devices)) == 1:
+                break                                          # one card: every root is the same memory
+        return {"value": round(steps * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt / steps * 1e3, 4),
+                "mode": mode, "gather": {fr._capi.FR_GATHER_PEER: "peer", fr._capi.FR_GATHER_RCCL: "rccl"}.get(used, str(used)),
+                "gather_asked": gather, "parts": n, "devices": sorted(set(devices)), "slots": slots if mode == "sequence" else 1,
+                "lanes": lanes if mode == "sequence" else 1, "last_part_kernel_ms": part_ms, "exchange_verified": ok}
+    finally:
+        node.close()
+
+
+def node_matrix(fr, torch, w, args, n_gpus) -> dict:
+    """Every (gather, mode) pair the box allows, each its own fr_node; failures are recorded, not raised."""
+    devices = [d for d in range(n_gpus) for _ in range(max(1, args.node_parts))]
+    if args.same_device:
+        devices = [0] * len(devices)
+    distinct = len(set(devices)) == len(devices)
+    slots = args.node_slots or (2 if len(devices) <= 2 else min(8, len(devices)))
+    lanes = args.node_lanes or 2
+    gathers = ["peer"] + (["rccl"] if (distinct and len(devices) > 1) else [])
+    out = {"devices": devices, "runs": []}
+    for g in gathers:
+        for mode in ("sequence", "frame"):
+            try:
+                out["runs"].append(node_measure(fr, torch, w, devices, args.steps, args.warmup, mode, g, slots, lanes, args.options))
+            except Exception as e:  # noqa: BLE001  (an informational leg must not take the line down)
+                out["runs"].append({"mode": mode, "gather_asked": g, "error": str(e)[:400]})
+    if len(devices) == 1:
+        # one card, one part: the whole RCCL frame path through a one-rank communicator (tuning "rccl_loopback")
+        try:
+            out["runs"].append(dict(node_measure(fr, torch, w, devices, args.steps, args.warmup, "sequence", "rccl", slots, lanes,
+                                                 args.options, loopback=True), note="rccl_loopback: one-rank communicator, strips sent to self"))
+        except Exception as e:  # noqa: BLE001
+            out["runs"].append({"mode": "sequence", "gather_asked": "rccl (loopback)", "error": str(e)[:400]})
+    return out
+
+
+def node_host(args) -> None:
+    """`python bench.py --gpus N --host node`: ONE process, fr_node over devices 0..N-1 through ctypes."""
+    import torch
+    import fractalrenderer_amd as fr
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    have = torch.cuda.device_count()
+    if args.gpus > have and not args.same_device:
+        raise SystemExit(f"--gpus {args.gpus} but this process sees {have} device(s) (--same-device rehearses on cuda:0)")
+    w = WORKLOADS[args.workload]
+    W, H = w["W"], w["H"]
+    m = node_matrix(fr, torch, w, args, args.gpus)
+    want_g = "peer" if args.gather == "auto" else args.gather
+    head = next((r for r in m["runs"] if r.get("mode") == args.mode and r.get("gather_asked") == want_g and "value" in r), None)
+    if head is None:
+        head = next((r for r in m["runs"] if "value" in r), None)
+    if head is None:
+        raise SystemExit("fr_node: no run succeeded: " + json.dumps(m))
+    gbs = 16 * W * H / (head["ms_per_step"] * 1e-3) / 1e9
+    prec64 = w["precision"] == "F64"
+    line = {"metric": "Mpixels/s at 4096x4096 max_iter=1024; achieved HBM GB/s vs peak" if args.workload == "c2"
+                      else f"Mpixels/s ({args.workload})",
+            "value": head["value"], "unit": "Mpixels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if prec64 else "f32", "data": "synthetic", "host": "node",
+            "config": {"workload": w["desc"], "output": "RGBA f32 linear colour, 16 B/pixel, resident in HBM on the frame's root",
+                       "mode": head["mode"],
+                       "parallelism": f"ONE process, C ABI fr_node: {head['parts']} part(s) on device(s) {head['devices']}, one worker thread "
+                                      f"per part, row strips dealt round-robin, gather = {head['gather']}, {head['slots']} frame slot(s), "
+                                      f"{head['lanes']} render lane(s) per part" + (", roots rotating" if head["mode"] == "sequence" else ", root 0")},
+            "exchange_verified": all(r.get("exchange_verified", False) for r in m["runs"] if "value" in r),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                         "traffic": None, "kernel_ms": None,
+                         "note": "16 B/pixel over the WALL time per frame of this host (frames overlap: no per-launch duration); the "
+                                 "kernels are VALU-bound, see the default command's roofline_valu"},
+            "cpu_baseline": None,
+            "node": m}
+    print(json.dumps(line), flush=True)
+
+
 def main() -> None:
     argv = sys.argv[1:]
     args = parse_args(argv)
     # before torch is imported and before any HIP call: dmabuf IPC for RCCL's peer mappings (read at runtime init)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.host == "node":
+        if "WORLD_SIZE" in os.environ:
+            raise SystemExit("--host node is ONE process: start it from a bare shell, not under torch.distributed.run")
+        if "kernel" in WORKLOADS[args.workload]:
+            raise SystemExit("kernel workloads are single-context")
+        node_host(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args, argv))
     if args.cpu_rehearsal:
@@ -461,9 +622,14 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    host_group = None
+    node_leg = world > 1 and os.environ.get("FR_BENCH_NODE_LEG", "1") != "0"
     if world > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+            if node_leg:
+                host_group = dist.new_group(backend="gloo")   # a HOST-side barrier for the fr_node leg: an RCCL barrier would
+                                                              # keep a spinning kernel on every waiting rank's GPU
         else:
             dist.init_process_group(args.dist_backend)
 
@@ -676,6 +842,27 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Informational, after the timed region: the same frames through the C ABI's multi-GPU host (fr_node: ONE process --
+    # this one, rank 0 -- driving all N devices, worker thread per device, frame slots, render lanes, both gathers), while
+    # the other ranks wait at a host-side barrier with idle GPUs.  Never the headline; failures are recorded, not raised.
+    fr_node_obj = None
+    if node_leg:
+        torch.cuda.synchronize()
+        dist.barrier(group=host_group)
+        if rank == 0:
+            leg = argparse.Namespace(**vars(args))
+            leg.steps, leg.warmup = min(args.steps, 200), min(max(args.warmup, 2), 20)
+            try:
+                if not args.same_device and torch.cuda.device_count() < world:
+                    raise RuntimeError(f"rank 0 sees {torch.cuda.device_count()} device(s), needs {world}")
+                fr_node_obj = node_matrix(fr, torch, w, leg, world)
+                fr_node_obj["note"] = ("informational: ONE process (rank 0) drives all devices through the C ABI's fr_node after the "
+                                       "timed region, the other ranks idle at a gloo barrier; per run: K frames, wall time, verified "
+                                       "bitwise against fr_render on every root")
+            except Exception as e:  # noqa: BLE001
+                fr_node_obj = {"error": str(e)[:400]}
+        dist.barrier(group=host_group)
+
     if rank == 0:
         mpx = args.steps * W * H / dt / 1e6
         out = {
@@ -764,6 +951,8 @@ def main() -> None:
             bytes_per_launch = bpp * W * fx.rows_local
             gbs = bytes_per_launch / (sum(ms) / len(ms) * 1e-3) / 1e9 if ms else 0.0
             out["exchange_verified"] = exchange_verified     # gathered frames == direct single-GPU render, on every rank
+            if fr_node_obj is not None:
+                out["fr_node"] = fr_node_obj
             out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
                                "kernel_ms": round(sum(ms) / len(ms), 4) if ms else None,
