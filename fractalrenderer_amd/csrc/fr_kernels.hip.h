@@ -53,6 +53,9 @@
 #ifndef FR_POOL64_WAVES
 #define FR_POOL64_WAVES 8
 #endif
+#ifndef FR_POOL_DEFER
+#define FR_POOL_DEFER 1      /* lane pool: escapes found at the end of an unchecked stretch are located later, 64 at a time */
+#endif
 
 namespace fr {
 
@@ -1862,6 +1865,23 @@ __device__ __forceinline__ void locate_escapes(T sX, T sYd, T sx2, T sy2d, const
  *     shaded, stored (16-byte scattered stores; neighbours in tile order finish close in time and
  *     merge in L2) and refilled together, so the per-pixel code runs reasonably full.
  * Results are bit-identical to the tile pass: same per-lane operation sequence. */
+/* DEFERRED LOCATION of escapes (round 4).  An unchecked stretch that ends with some lanes beyond the bailout used to be
+ * followed by locate_escapes: the WHOLE wave replayed the stretch, tested, for the two or three lanes that needed their
+ * escape index -- and after two such stretches in a row the wave fell back to per-update tests for everybody (6 VALU + 4-6
+ * scalar instructions and two branches per update instead of 6 VALU): on escape-dense survivors (the C5 view, the C3 dust)
+ * 41 % of all updates ran tested and another 14 % were replayed.  Now the escaped lanes' stretch-start states go into a
+ * per-wave ring in LDS {pixel, iteration index at the stretch's start, X, Yd (, cx, cyd)}, the lanes are free for the next
+ * refill at once, the wave STAYS in unchecked stretches, and whenever 64 entries are queued lane l takes entry l and the
+ * wave runs ONE tested replay at full occupancy (at most the longest stretch among them: 16-64 updates), shades and stores.
+ * Same operations on the same values in the same order as the stretch itself: the planes do not change by a bit. */
+constexpr int kDeferSlots = 128;         /* < 64 entries wait, a stretch adds at most 64 */
+template <typename T, int NF>
+struct DeferRing {
+    uint32_t pix[kDeferSlots];
+    int32_t i0[kDeferSlots];             /* index of the stretch's first update in the sample's own count */
+    T f[NF][kDeferSlots];                /* X, Yd (, cx, cyd) at the stretch's start */
+};
+
 template <typename T>
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
@@ -1892,6 +1912,12 @@ pool_kernel(const LaunchArgs A)
     stage_interior<T, FRACTAL>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
+#if FR_POOL_DEFER
+    __shared__ DeferRing<T, NF> defer_rings[kWavesPerBlock];
+    DeferRing<T, NF>& D = defer_rings[threadIdx.x >> 6];
+    uint32_t dhead = 0, dtail = 0;       /* wave-uniform entry counters */
+    bool finishing = false;              /* every lane retired and the queue dry: only the ring is left */
+#endif
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const int max_iter = A.max_iter;                     /* wave-uniform: straight from the kernel arguments */
@@ -1944,10 +1970,66 @@ pool_kernel(const LaunchArgs A)
      * Re z and Im z, block by block) after it last saw a lane back at its snapshot; "this wave has closed a cycle" */
     uint32_t alert = 0, n_closed = 0;
     bool ever_closed = false;
+#if FR_POOL_DEFER
+    bool dry = false, fast = fast_ok;    /* a dirty stretch costs a ring entry per escaped lane: no reason to start tested */
+#else
     bool dry = false, fast = false;
+#endif
 
     FR_STAMP_DECL
     for (;;) {
+#if FR_POOL_DEFER
+        /* ---- deferred escapes: 64 queued (or the wave is leaving) -> one tested replay at full occupancy ---- */
+        while (dtail - dhead >= 64u || (finishing && dtail != dhead)) {
+            const uint32_t count = dtail - dhead < 64u ? dtail - dhead : 64u;
+            const bool have = lane < count;
+            const uint32_t slot = (dhead + lane) & (uint32_t)(kDeferSlots - 1);
+            Orbit<T> t;
+            t.X = have ? D.f[0][slot] : T(0);
+            t.Yd = have ? D.f[1][slot] : T(0);
+            if constexpr (Form<FRACTAL>::per_sample_c) { t.cx = have ? D.f[2][slot] : T(0); t.cyd = have ? D.f[3][slot] : T(0); }
+            else { t.cx = have ? (T)S.julia_cx : T(0); t.cyd = have ? T(2) * (T)S.julia_cy : T(0); }
+            t.x2 = t.X * t.X;
+            t.y2d = t.Yd * t.Yd;
+            const uint32_t rpix = D.pix[slot];
+            const int ri0 = D.i0[slot];
+            bool open = have;
+            uint32_t ek = 0u;
+            T er = T(0);
+            uint64_t pending = __builtin_amdgcn_ballot_w64(have);
+            uint32_t k = 0;
+            do {
+                orbit_step<T, Form<FRACTAL>::abs_step>(t);
+                const T r = orbit_r2x4(t);
+                const bool e = open && r > B2x4;
+                if (e) { ek = k; er = r; open = false; }
+                pending &= ~__builtin_amdgcn_ballot_w64(e);
+                ++k;
+            } while (pending != 0ull && k < (uint32_t)max_iter);
+#ifdef FR_STAMP_TESTED
+            st_acc[3] += k;              /* diagnostic: updates of deferred replays */
+#endif
+            if (have) {
+                /* an escape at or past the sample's last update is no escape: it ran its max_iter updates */
+                const int idx = ri0 + (int)ek;
+                const bool esc = !open && idx < max_iter;
+                const int r_it = esc ? idx : max_iter;
+                const T r_r2 = esc ? T(0.25) * er : T(0);
+                T nu;
+                float rgb[3];
+                shade<T, FRACTAL>(*kargs(), S, lg, r_it, r_r2, want_nu, want_rgb, nu, rgb);
+                KArgs K = kargs();
+                if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
+                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
+                if (K->rgba) K->rgba[rpix] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+                if (K->nu) reinterpret_cast<T*>(K->nu)[rpix] = nu;
+                if (K->iter) K->iter[rpix] = r_it;
+            }
+            dhead += count;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (finishing) break;
+#endif
         /* ---- retire: shade and store the finished lanes ---- */
         FR_STAMP_BEGIN();
         const uint64_t finm = __builtin_amdgcn_ballot_w64(fin != 0u);
@@ -2040,7 +2122,11 @@ pool_kernel(const LaunchArgs A)
 #endif
         FR_STAMP_END(2);
         const uint64_t active = __builtin_amdgcn_ballot_w64(pixel != kInvalidPixel);
+#if FR_POOL_DEFER
+        if (active == 0ull) { finishing = true; continue; }  /* queue dry and every lane retired: flush the ring, leave */
+#else
         if (active == 0ull) break;                           /* queue dry and every lane retired */
+#endif
         const uint32_t nactive = (uint32_t)__builtin_popcountll(active);
         /* a wave that can no longer refill is on the critical path of the launch: give it issue priority */
         if (dry) __builtin_amdgcn_s_setprio(3);
@@ -2198,7 +2284,11 @@ pool_kernel(const LaunchArgs A)
                 break;
             }
             if (fast) {
+#if FR_POOL_DEFER
+                const T sX = o.X, sYd = o.Yd;
+#else
                 const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
+#endif
                 /* after 2 (6) clean stretches in a row the wave runs 2 (4) blocks per snapshot / test (a half, a
                  * quarter of that overhead on the long interior runs that dominate deep views); a dirty one resets it */
                 uint32_t reps = streak >= 6u ? 4u : (streak >= 2u ? 2u : 1u);
@@ -2236,7 +2326,32 @@ pool_kernel(const LaunchArgs A)
                 }
                 const bool bad = !(orbit_r2x4(o) <= B2x4);
                 const uint64_t badm = __builtin_amdgcn_ballot_w64(bad);
+                bool ring_full = false;
                 if (badm != 0ull) {
+#if FR_POOL_DEFER
+                    /* dirty stretch: the escaped lanes' stretch-start states go to the ring (located 64 at a time, see
+                     * DeferRing), the lanes are free; everybody else's progress counts and the wave stays unchecked */
+                    if (bad) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(badm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)badm, 0u));
+                        const uint32_t slot = (dtail + rank) & (uint32_t)(kDeferSlots - 1);
+                        D.pix[slot] = pixel;
+                        D.i0[slot] = (int)(wclock - (deadline - (uint32_t)max_iter));
+                        D.f[0][slot] = sX;
+                        D.f[1][slot] = sYd;
+                        if constexpr (Form<FRACTAL>::per_sample_c) { D.f[2][slot] = o.cx; D.f[3][slot] = o.cyd; }
+                        pixel = kInvalidPixel;
+                        o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
+                    }
+                    const uint32_t nbad = (uint32_t)__builtin_popcountll(badm);
+                    dtail += nbad;
+                    newly += nbad;
+                    streak = 0;
+                    ring_full = dtail - dhead >= 64u;
+                    __builtin_amdgcn_wave_barrier();
+#ifdef FR_STAMP_TESTED
+                    st_acc[2] += len;        /* diagnostic: updates of dirty unchecked stretches */
+#endif
+#else
                     /* dirty stretch: locate the escaped lanes' updates (locate_escapes), keep everybody else's progress */
                     uint32_t ek; T er;
                     locate_escapes<T, Form<FRACTAL>::abs_step>(sX, sYd, sx2, sy2d, o.cx, o.cyd, B2x4, bad, badm, len, ek, er);
@@ -2255,6 +2370,7 @@ pool_kernel(const LaunchArgs A)
                     streak = 0;
                     /* escape-dense neighbourhood: per-update tests are cheaper than locating block after block */
                     if (++dirty_run >= 2u) fast = false;
+#endif
                 } else {
                     ++streak;
                     dirty_run = 0;
@@ -2268,6 +2384,7 @@ pool_kernel(const LaunchArgs A)
                     /* nothing seen and no snapshot due (the usual case where nothing closes): two scalar tests */
                     if (saw || (int32_t)(wclock - next_snap) >= 0) { cyc |= seen; close_cycles(exact ? wclock - snap_time : 0u); }
                 }
+                if (ring_full) break;        /* 64 deferred escapes queued: replay them (top of the loop) before more arrive */
                 continue;
             }
             /* tested stretch: up to the next deadline, at most one block.  The loop carries a countdown and
