@@ -29,7 +29,8 @@
  *     instead), so no per-lane "active" predicate
  *     exists in the loop; a tile wave leaves the loop as soon as the ballot of finished lanes is full
  *     (wave-uniform early-out); where escape is absorbing, waves run UNCHECKED blocks of 16 updates
- *     (6 VALU ops each) with rollback + tested replay on a dirty block;
+ *     (6 VALU ops each); a dirty block is rolled back and replayed tested (tile pass), or -- lane pool -- only its escaped
+ *     lanes are, later, 64 of them at a time from a ring in LDS (DeferRing), while the wave runs on unchecked;
  *   - scalar instructions share one issue port per CU: the tested loops carry a countdown and one
  *     vector-compare branch, nothing else ("Scalar issue is a roofline too");
  *   - the arithmetic is the reference's, one rounding per operation, NO contraction of the
@@ -50,12 +51,6 @@
 #include "fr_internal.h"
 
 #pragma clang fp contract(off)
-#ifndef FR_POOL64_WAVES
-#define FR_POOL64_WAVES 8
-#endif
-#ifndef FR_POOL_DEFER
-#define FR_POOL_DEFER 1      /* lane pool: escapes found at the end of an unchecked stretch are located later, 64 at a time */
-#endif
 
 namespace fr {
 
@@ -1820,33 +1815,6 @@ tile_lean_kernel(const LaunchArgs A)
     FR_STAMP_WRITE(A, lane);
 }
 
-/* A dirty unchecked stretch (some lane of `badm` escaped inside it) used to be rolled back as a whole and replayed with
- * per-update tests: the kmax updates of every OTHER lane were thrown away and run again.  Only the escaped lanes need the
- * replay -- to learn the index and |z|^2 of their escaping update; everybody else's state after the stretch is already
- * right (nothing of it depends on another lane).  So the snapshot is replayed in scratch registers, tested, until every
- * lane of badm has been located (the same operations in the same order: bit-identical to the stretch itself, and a lane
- * that is beyond the bailout at the end has crossed it at a finite update, escape being absorbing), and the stretch
- * counts.  k: offset of the escaping update inside the stretch (lanes of badm only), r2x4: 4 |z|^2 there. */
-template <typename T, bool ABS>
-__device__ __forceinline__ void locate_escapes(T sX, T sYd, T sx2, T sy2d, const T cx, const T cyd, const T B2x4,
-                                               const bool bad, uint64_t pending, const uint32_t kmax,
-                                               uint32_t& esc_k, T& esc_r2x4)
-{
-    Orbit<T> t;
-    t.X = sX; t.Yd = sYd; t.x2 = sx2; t.y2d = sy2d; t.cx = cx; t.cyd = cyd;
-    bool open = bad;
-    esc_k = 0u; esc_r2x4 = T(0);
-    uint32_t k = 0;
-    do {
-        orbit_step<T, ABS>(t);
-        const T r = orbit_r2x4(t);
-        const bool e = open && r > B2x4;
-        if (e) { esc_k = k; esc_r2x4 = r; open = false; }
-        pending &= ~__builtin_amdgcn_ballot_w64(e);
-        ++k;
-    } while (pending != 0ull && k < kmax);
-}
-
 /* ---- lane pool ------------------------------------------------------------------------------------
  * Persistent LANES: a lane that finishes its sample is refilled with the next survivor record of the wave's
  * reserve (blocks of 64 records claimed a run at a time from the region queues of the survivor stream),
@@ -1898,10 +1866,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
  * pool; it lost to tile pass + pool on every workload and left the product in round 3: DESIGN.md section 7.) */
 template <typename T, int FRACTAL, bool PERIOD = false>
 __global__ void __launch_bounds__(kBlockThreads)
-/* VGPRs are handed out in granules of 16 on gfx950 (measured: the 68-VGPR fp64 instantiation runs 6 workgroups per CU, not
- * the 7 its count suggests; tools/timeline.py, live waves per tenth of a pass): 64 is what 8 waves per SIMD take.  The plain
- * fp64 instantiation fits them (one SGPR spill, no scratch); the cycle-closing one does not (45 VGPRs to scratch) and stays at 6. */
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 && !PERIOD ? FR_POOL64_WAVES : 1)))
+/* VGPRs are handed out in granules of 16 on gfx950 (measured in round 3: a 68-VGPR fp64 instantiation ran 6 workgroups per
+ * CU, not the 7 its count suggests).  Round 3 held the plain fp64 instantiation at 64 (8 waves per SIMD; +-0 to -2 %); with
+ * the deferred-escape ring (22 KB of LDS per workgroup: 7 at most) it takes 70 and runs 6 -- budgets of 5, 6 and "8" measured
+ * the same (profiles/r04_pool_deferred_escapes.txt). */
 pool_kernel(const LaunchArgs A)
 {
     constexpr int NF = RecFields<FRACTAL>::n;
@@ -1912,12 +1880,10 @@ pool_kernel(const LaunchArgs A)
     stage_interior<T, FRACTAL>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
-#if FR_POOL_DEFER
     __shared__ DeferRing<T, NF> defer_rings[kWavesPerBlock];
     DeferRing<T, NF>& D = defer_rings[threadIdx.x >> 6];
     uint32_t dhead = 0, dtail = 0;       /* wave-uniform entry counters */
     bool finishing = false;              /* every lane retired and the queue dry: only the ring is left */
-#endif
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const int max_iter = A.max_iter;                     /* wave-uniform: straight from the kernel arguments */
@@ -1970,15 +1936,10 @@ pool_kernel(const LaunchArgs A)
      * Re z and Im z, block by block) after it last saw a lane back at its snapshot; "this wave has closed a cycle" */
     uint32_t alert = 0, n_closed = 0;
     bool ever_closed = false;
-#if FR_POOL_DEFER
     bool dry = false, fast = fast_ok;    /* a dirty stretch costs a ring entry per escaped lane: no reason to start tested */
-#else
-    bool dry = false, fast = false;
-#endif
 
     FR_STAMP_DECL
     for (;;) {
-#if FR_POOL_DEFER
         /* ---- deferred escapes: 64 queued (or the wave is leaving) -> one tested replay at full occupancy ---- */
         while (dtail - dhead >= 64u || (finishing && dtail != dhead)) {
             const uint32_t count = dtail - dhead < 64u ? dtail - dhead : 64u;
@@ -2029,7 +1990,6 @@ pool_kernel(const LaunchArgs A)
             __builtin_amdgcn_wave_barrier();
         }
         if (finishing) break;
-#endif
         /* ---- retire: shade and store the finished lanes ---- */
         FR_STAMP_BEGIN();
         const uint64_t finm = __builtin_amdgcn_ballot_w64(fin != 0u);
@@ -2122,11 +2082,7 @@ pool_kernel(const LaunchArgs A)
 #endif
         FR_STAMP_END(2);
         const uint64_t active = __builtin_amdgcn_ballot_w64(pixel != kInvalidPixel);
-#if FR_POOL_DEFER
         if (active == 0ull) { finishing = true; continue; }  /* queue dry and every lane retired: flush the ring, leave */
-#else
-        if (active == 0ull) break;                           /* queue dry and every lane retired */
-#endif
         const uint32_t nactive = (uint32_t)__builtin_popcountll(active);
         /* a wave that can no longer refill is on the critical path of the launch: give it issue priority */
         if (dry) __builtin_amdgcn_s_setprio(3);
@@ -2253,7 +2209,6 @@ pool_kernel(const LaunchArgs A)
         };
         uint32_t clean = 0;            /* tested updates since the last escape */
         uint32_t streak = 0;           /* clean unchecked blocks in a row */
-        uint32_t dirty_run = 0;        /* dirty unchecked stretches in a row */
         /* Every wave must reach its exit whatever happens to the bookkeeping above: a running lane finishes within
          * max_iter updates, so a stretch loop that has run max_iter + 4096 updates without reaching its goal is a bug.
          * It then says so (the host fails the render: FR_ERR_INTERNAL) and retires what it holds as interior. */
@@ -2284,11 +2239,7 @@ pool_kernel(const LaunchArgs A)
                 break;
             }
             if (fast) {
-#if FR_POOL_DEFER
                 const T sX = o.X, sYd = o.Yd;
-#else
-                const T sX = o.X, sYd = o.Yd, sx2 = o.x2, sy2d = o.y2d;
-#endif
                 /* after 2 (6) clean stretches in a row the wave runs 2 (4) blocks per snapshot / test (a half, a
                  * quarter of that overhead on the long interior runs that dominate deep views); a dirty one resets it */
                 uint32_t reps = streak >= 6u ? 4u : (streak >= 2u ? 2u : 1u);
@@ -2328,7 +2279,6 @@ pool_kernel(const LaunchArgs A)
                 const uint64_t badm = __builtin_amdgcn_ballot_w64(bad);
                 bool ring_full = false;
                 if (badm != 0ull) {
-#if FR_POOL_DEFER
                     /* dirty stretch: the escaped lanes' stretch-start states go to the ring (located 64 at a time, see
                      * DeferRing), the lanes are free; everybody else's progress counts and the wave stays unchecked */
                     if (bad) {
@@ -2351,29 +2301,8 @@ pool_kernel(const LaunchArgs A)
 #ifdef FR_STAMP_TESTED
                     st_acc[2] += len;        /* diagnostic: updates of dirty unchecked stretches */
 #endif
-#else
-                    /* dirty stretch: locate the escaped lanes' updates (locate_escapes), keep everybody else's progress */
-                    uint32_t ek; T er;
-                    locate_escapes<T, Form<FRACTAL>::abs_step>(sX, sYd, sx2, sy2d, o.cx, o.cyd, B2x4, bad, badm, len, ek, er);
-#ifdef FR_STAMP_TESTED
-                    st_acc[2] += len;        /* diagnostic: updates of dirty unchecked stretches */
-#endif
-                    if (bad) {
-                        /* an escape at or past the lane's deadline is no escape: the sample ran its max_iter updates */
-                        const int idx = (int)(wclock + ek - (deadline - (uint32_t)max_iter));
-                        esc_i = idx < max_iter ? idx : max_iter;
-                        esc_r2 = idx < max_iter ? T(0.25) * er : T(0);
-                        fin = 1u;
-                        o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
-                    }
-                    newly += (uint32_t)__builtin_popcountll(badm);
-                    streak = 0;
-                    /* escape-dense neighbourhood: per-update tests are cheaper than locating block after block */
-                    if (++dirty_run >= 2u) fast = false;
-#endif
                 } else {
                     ++streak;
-                    dirty_run = 0;
                 }
                 wclock += len;
                 /* lanes at or past their deadline that are still running never escaped -> interior */

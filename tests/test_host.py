@@ -561,11 +561,13 @@ def test_hot_kernels_keep_their_register_budget(fr):
     budget = {   # mangled name: (max VGPRs, min waves/SIMD, max SGPR spills)
         # lane pool: queue parameters, stream description and output planes are re-read from the kernel arguments where
         # they are used (kargs()), so nothing spills -- v_readlane / v_writelane are VALU issue slots
-        # (VGPRs come in granules of 16 on gfx950: 64 is what 8 waves per SIMD take; the kernel is held there by amdgpu_waves_per_eu)
-        "_ZN2fr11pool_kernelIdLi0ELb0EEEvNS_10LaunchArgsE": (64, 8, 2),    # fp64 Mandelbrot lane pool (C2/C4/C5)
-        "_ZN2fr11pool_kernelIdLi0ELb1EEEvNS_10LaunchArgsE": (80, 6, 0),    # ... with cycle closing (the default)
+        # (VGPRs come in granules of 16 on gfx950; round 4's deferred-escape ring -- 22 KB of LDS per workgroup -- and its replay
+        # registers put the fp64 pool at 70 VGPRs = 6 resident workgroups per CU; 5, 6 and 8 waves per SIMD measured the same)
+        "_ZN2fr11pool_kernelIdLi0ELb0EEEvNS_10LaunchArgsE": (80, 6, 0),    # fp64 Mandelbrot lane pool (C2/C4/C5)
+        "_ZN2fr11pool_kernelIdLi0ELb1EEEvNS_10LaunchArgsE": (80, 6, 12),   # ... with cycle closing (the default; the ring's
+                                                                            # counters pushed 12 SGPRs out: measured -6 % all the same)
         "_ZN2fr11pool_kernelIfLi1ELb0EEEvNS_10LaunchArgsE": (64, 6, 0),    # fp32 Julia lane pool (C3)
-        "_ZN2fr11pool_kernelIfLi1ELb1EEEvNS_10LaunchArgsE": (64, 6, 0),    # ... with cycle closing (the default)
+        "_ZN2fr11pool_kernelIfLi1ELb1EEEvNS_10LaunchArgsE": (64, 6, 4),    # ... with cycle closing (the default)
         # lean tile kernel, two sub-tiles per trip (the default tile pass): 5 workgroups per CU = 5 waves per SIMD
         "_ZN2fr16tile_lean_kernelIdLi0ELb0ELi2EEEvNS_10LaunchArgsE": (96, 5, 16),  # fp64 Mandelbrot, staged (C2/C4/C5)
         "_ZN2fr16tile_lean_kernelIdLi0ELb1ELi2EEEvNS_10LaunchArgsE": (96, 5, 16),  # one-pass frames (C1), cycle closing
