@@ -154,6 +154,7 @@ SIGNATURES = {
 INTERNAL_SIGNATURES = {
     "fr_ctx_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "fr_export8_thresholds": (None, [_P(C.c_float)]),          # fr_internal.h: byte thresholds of the 8-bit export
+    "fr_export8_thresholds_host_powf": (None, [_P(C.c_float)]),
     "fr_node_rccl_selftest": (C.c_int, [C.c_int, C.c_size_t, _P(C.c_int)]),
     "fr_ctx_last_pool_closing": (C.c_int, [C.c_void_p]),
     "fr_node_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),

@@ -75,7 +75,7 @@ struct fr_ctx {
                                  * own stream (exports, colorize) behind it */
     /* automatic cycle closing of the lane pool (pool_wants_cycle_closing) */
     uint32_t render_seq;        /* renders enqueued on this context */
-    uint64_t probe_key;         /* what the context renders (fractal, precision, max_iter, geometry) */
+    uint64_t probe_key;         /* what the context renders (fractal, precision, max_iter, geometry, coarse view) */
     int probe_mode;             /* 0 LOOK: every render's pool looks; 1 SKIP: none does, skip_left to go; 2 WAIT: one look is in
                                  * flight (render probe_seq), nobody else looks until its verdict is back */
     uint32_t probe_first;       /* LOOK: first render of the run of looks; WAIT: the one look */
@@ -452,7 +452,15 @@ static bool pool_wants_cycle_closing(fr_ctx* c, const fr_params* p, uint32_t W, 
 {
     if (c->tune_periodicity != 0) return c->tune_periodicity > 0;          /* explicit: on (any window) or off */
     uint64_t key = 1469598103934665603ull;
-    const uint64_t parts[5] = {(uint64_t)p->fractal_type, (uint64_t)p->precision, (uint64_t)p->max_iterations, W, rows};
+    /* ... and WHERE it looks, coarsely: the octave of the zoom, the centre in units of that octave's view height, the Julia
+     * constant to 1/64 -- a sequence that leaves a dust for an interior-heavy view (or pans by a view, or zooms by 2x) starts
+     * looking again at once instead of finishing its 14 frames of not looking */
+    int zexp = 0;
+    (void)frexp(fabs(p->zoom), &zexp);
+    const double cell = ldexp(1.0, zexp);
+    const uint64_t parts[10] = {(uint64_t)p->fractal_type, (uint64_t)p->precision, (uint64_t)p->max_iterations, W, rows,
+                                (uint64_t)(int64_t)zexp, (uint64_t)(int64_t)floor(p->center_x / cell), (uint64_t)(int64_t)floor(p->center_y / cell),
+                                (uint64_t)(int64_t)floor(p->julia_c_real * 64.0), (uint64_t)(int64_t)floor(p->julia_c_imag * 64.0)};
     for (uint64_t v : parts) key = (key ^ v) * 1099511628211ull;
     if (key != c->probe_key) { c->probe_key = key; c->probe_mode = 0; c->probe_first = 0; }
     /* the verdict the device forwarded last: (render number << 1) | "closing cycles paid" (an eighth of the pool's records

@@ -296,12 +296,29 @@ static void palette_table_fill(int shader, int mode, fr_palette_table* t)
 
 /* ---- 8-bit export: exact bytes --------------------------------------------------------------------
  * The reference's byte is (uint8)(powf(a, 1/2.2f) * 255.0f) with a = aces(v) in [0, 1] (src/vk_engine.cpp:1366-1368).
- * As a function of a it is monotone non-decreasing (powf is; checked exhaustively, over every float of [0, 1], by
+ * As a function of a it is monotone non-decreasing (checked exhaustively, over every float of [0, 1], by
  * tests/test_host.py::test_export8_thresholds_against_an_exhaustive_scan), so it is fully described by 255
- * thresholds: t[b] = the smallest float whose byte is >= b, found here by bisection over the float bit patterns with
- * the host's powf -- the libm the CPU restatement of the reference loop uses.  The export kernel keeps its fast
- * exp2(log2 a / 2.2) estimate and corrects it by comparing a with t[estimate] and t[estimate + 1]: the bytes are then
- * those of the powf form, for every input.  t[0] = 0, t[256] = +inf. */
+ * thresholds: t[b] = the smallest float whose byte is >= b.  The export kernel keeps its fast exp2(log2 a / 2.2) estimate
+ * and corrects it by comparing a with t[estimate] and t[estimate + 1]: the bytes are then those of the powf form, for every
+ * input.  t[0] = 0, t[256] = +inf.
+ *
+ * WHICH powf.  The last bit of powf depends on the C runtime (the reference builds against MSVC's; glibc's is one ulp off
+ * the correctly rounded value at a = 0x3C364A2A, exactly where byte 32 becomes byte 33), so thresholds found by bisection
+ * with the deployment host's libm -- rounds 2 and 3 -- differ between hosts and from the reference's by a float here and
+ * there.  Since round 4 the table is BAKED IN: generated once from the correctly rounded single-precision power
+ * (tools/gen_export8_table.py, mpmath at 200 bits), the same on every host.  "Exact" means exact with respect to that
+ * definition; the host-libm bisection is kept (fr_export8_thresholds_host_powf) so that the tests can report where a host
+ * differs. */
+static const uint32_t kExport8Table[256] = {
+#include "fr_export8_table.inc"
+};
+
+void fr_export8_thresholds(float t[257])
+{
+    memcpy(t, kExport8Table, sizeof(kExport8Table));
+    t[256] = INFINITY;
+}
+
 static uint32_t export8_byte(uint32_t bits)
 {
     float a;
@@ -309,7 +326,7 @@ static uint32_t export8_byte(uint32_t bits)
     return (uint32_t)(powf(a, 1.0f / 2.2f) * 255.0f);
 }
 
-void fr_export8_thresholds(float t[257])
+void fr_export8_thresholds_host_powf(float t[257])
 {
     t[0] = 0.0f;
     for (uint32_t b = 1; b < 256; ++b) {

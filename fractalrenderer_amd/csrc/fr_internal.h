@@ -25,8 +25,11 @@ int32_t fr_deep_zoom_reference_length(const fr_params* p);
 void* fr_ctx_stream_handle(fr_ctx* ctx);
 int   fr_ctx_device(const fr_ctx* ctx);
 
-/* thresholds of the 8-bit export (fr_host.c): t[b] = smallest float a in [0, 1] with (uint8)(powf(a, 1/2.2f) * 255) >= b */
+/* thresholds of the 8-bit export (fr_host.c): t[b] = smallest float a in [0, 1] with (uint8)(powf(a, 1/2.2f) * 255) >= b, powf
+ * being the correctly rounded single-precision power (a baked table: the same on every host); _host_powf: the same by
+ * bisection with the deployment host's libm, for the tests to report where a host's powf differs */
 void fr_export8_thresholds(float t[257]);
+void fr_export8_thresholds_host_powf(float t[257]);
 
 /* ---- palette knot table: what the kernels stage into LDS ------------------------------
  * Every palette of the two shaders is "warp t, then a 5-knot piece-wise linear ramp"

@@ -359,11 +359,12 @@ def mapped_runtimes() -> list:
     return [ln for ln in buf.value.decode().split("\n") if ln]
 
 
-def export8_thresholds() -> np.ndarray:
+def export8_thresholds(host_powf: bool = False) -> np.ndarray:
     """fr_export8_thresholds (internal): t[b] = the smallest float32 a of [0, 1] with (uint8)(powf(a, 1/2.2f) * 255) >= b,
-    b = 0..255, and t[256] = inf -- the table the 8-bit export kernel corrects its gamma estimate against."""
+    b = 0..255, and t[256] = inf -- the table the 8-bit export kernel corrects its gamma estimate against: baked in, from the
+    correctly rounded single-precision power (tools/gen_export8_table.py).  host_powf: the same by bisection with this host's libm."""
     t = (C.c_float * 257)()
-    _capi.lib().fr_export8_thresholds(t)
+    (_capi.lib().fr_export8_thresholds_host_powf if host_powf else _capi.lib().fr_export8_thresholds)(t)
     return np.frombuffer(t, dtype=np.float32).copy()
 
 

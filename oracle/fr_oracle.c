@@ -476,6 +476,15 @@ static float half_to_float(uint16_t h)
     return out;
 }
 
+/* powf of the 8-bit export.  The reference calls its C runtime's powf (MSVC's; src/vk_engine.cpp:1367), and runtimes differ in
+ * the last bit of powf: glibc's is one ulp off the correctly rounded result at a = 0x3C364A2A, where that decides between byte
+ * 32 and byte 33.  The checker therefore uses the one value that does not depend on a runtime -- the CORRECTLY ROUNDED
+ * single-precision power -- computed as the double-precision pow (error < 1 ulp of double) rounded to float, which is the
+ * correctly rounded float unless a^e lies within 2^-29 (relative) of a rounding boundary of float; the library's table is
+ * generated from a 200-bit power (tools/gen_export8_table.py), and the exhaustive scan below holds this function against it
+ * at every float of [0, 1]. */
+static inline float powf_cr(float a, float e) { return (float)pow((double)a, (double)e); }
+
 /* src/vk_engine.cpp:1355-1371 */
 void fro_export_rgb8(const float* rgba, int32_t W, int32_t H, uint8_t* rgb8, int32_t through_half)
 {
@@ -488,7 +497,7 @@ void fro_export_rgb8(const float* rgba, int32_t W, int32_t H, uint8_t* rgb8, int
                 float v = rgba[src + c];
                 if (through_half) v = half_to_float(float_to_half_rne(v));
                 v = aces(v);                                       /* :1366 */
-                v = powf(v, gamma);                                /* :1367 */
+                v = powf_cr(v, gamma);                             /* :1367 */
                 rgb8[dst + c] = (uint8_t)(v * 255.0f);             /* :1368 */
             }
         }
@@ -519,11 +528,11 @@ int64_t fro_export8_scan(uint32_t first[256])
             uint32_t hi = lo + chunk - 1u;
             if (hi > last) hi = last;
             uint32_t prev = 0;
-            if (lo > 0) { const uint32_t pb = lo - 1u; float a; memcpy(&a, &pb, 4); prev = (uint32_t)(uint8_t)(powf(a, gamma) * 255.0f); }
+            if (lo > 0) { const uint32_t pb = lo - 1u; float a; memcpy(&a, &pb, 4); prev = (uint32_t)(uint8_t)(powf_cr(a, gamma) * 255.0f); }
             for (uint32_t bits = lo; ; bits++) {
                 float a;
                 memcpy(&a, &bits, 4);
-                const uint32_t by = (uint32_t)(uint8_t)(powf(a, gamma) * 255.0f);
+                const uint32_t by = (uint32_t)(uint8_t)(powf_cr(a, gamma) * 255.0f);
                 if (by < prev) bad++;
                 if (bits < mine[by]) mine[by] = bits;
                 prev = by;

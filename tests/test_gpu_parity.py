@@ -1280,6 +1280,20 @@ def test_automatic_cycle_closing_stops_looking_where_nothing_closes(fr):
         # a one-pass frame has no lane pool
         r.render(fr.FractalState(max_iterations=100), W, H, nu=torch.empty((H, W), dtype=torch.float64, device="cuda"))
         assert r.last_pool_closing() == -1
+        # a sequence that leaves the dust for a filled Julia set (same fractal, size, max_iter: only the view's constant
+        # changes) starts looking again at once, and keeps looking there
+        r.set_option("periodicity", 0)
+        looks = []
+        for _ in range(20):
+            r.render(dust["state"], W, H, fractal_type=dust["fractal_type"], precision=dust["precision"], nu=torch.empty((H, W), dtype=torch.float32, device="cuda"))
+            looks.append(r.last_pool_closing())
+        assert looks[-1] == 0 or sum(looks[-8:]) <= 2, looks                                 # not looking (any more)
+        rabbit = fr.FractalState(max_iterations=2048, center_x=0.0, julia_c_real=-0.123, julia_c_imag=0.745)
+        looks = []
+        for _ in range(6):
+            r.render(rabbit, W, H, fractal_type=fr.FractalType.JuliaSet, precision=fr.Precision.F32, nu=torch.empty((H, W), dtype=torch.float32, device="cuda"))
+            looks.append(r.last_pool_closing())
+        assert looks == [1] * 6, looks
 
 
 def test_plain_c_node_client_on_one_card(fr, tmp_path):

@@ -6,7 +6,7 @@ set -e
 REF="$1"; NAME="$2"; ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 TMP="$(mktemp -d)"; mkdir -p "$ROOT/build/ab" "$TMP/include" "$TMP/fractalrenderer_amd/csrc"
 if [ "$REF" = work ]; then
-  cp "$ROOT"/include/*.h "$TMP/include/"; cp "$ROOT"/fractalrenderer_amd/csrc/{*.c,*.cpp,*.h,*.hip,Makefile} "$TMP/fractalrenderer_amd/csrc/"
+  cp "$ROOT"/include/*.h "$TMP/include/"; cp "$ROOT"/fractalrenderer_amd/csrc/{*.c,*.cpp,*.h,*.hip,*.inc,Makefile} "$TMP/fractalrenderer_amd/csrc/"
 else
   for f in $(git -C "$ROOT" ls-tree -r --name-only "$REF" include fractalrenderer_amd/csrc); do git -C "$ROOT" show "$REF:$f" > "$TMP/$f"; done
 fi
