@@ -846,21 +846,36 @@ def main() -> None:
     # this one, rank 0 -- driving all N devices, worker thread per device, frame slots, render lanes, both gathers), while
     # the other ranks wait at a host-side barrier with idle GPUs.  Never the headline; failures are recorded, not raised.
     fr_node_obj = None
+    node_leg_stuck = False
     if node_leg:
         torch.cuda.synchronize()
         dist.barrier(group=host_group)
         if rank == 0:
             leg = argparse.Namespace(**vars(args))
             leg.steps, leg.warmup = min(args.steps, 200), min(max(args.warmup, 2), 20)
-            try:
-                if not args.same_device and torch.cuda.device_count() < world:
-                    raise RuntimeError(f"rank 0 sees {torch.cuda.device_count()} device(s), needs {world}")
-                fr_node_obj = node_matrix(fr, torch, w, leg, world)
-                fr_node_obj["note"] = ("informational: ONE process (rank 0) drives all devices through the C ABI's fr_node after the "
-                                       "timed region, the other ranks idle at a gloo barrier; per run: K frames, wall time, verified "
-                                       "bitwise against fr_render on every root")
-            except Exception as e:  # noqa: BLE001
-                fr_node_obj = {"error": str(e)[:400]}
+            # on a worker thread with a deadline: this leg has never run on more than one card, and a hang in it (a
+            # communicator that does not come up) must not take the measured headline with it
+            import threading
+            box = {}
+
+            def run_leg():
+                try:
+                    if not args.same_device and torch.cuda.device_count() < world:
+                        raise RuntimeError(f"rank 0 sees {torch.cuda.device_count()} device(s), needs {world}")
+                    m = node_matrix(fr, torch, w, leg, world)
+                    m["note"] = ("informational: ONE process (rank 0) drives all devices through the C ABI's fr_node after the "
+                                 "timed region, the other ranks idle at a gloo barrier; per run: K frames, wall time, verified "
+                                 "bitwise against fr_render on every root")
+                    box["obj"] = m
+                except Exception as e:  # noqa: BLE001
+                    box["obj"] = {"error": str(e)[:400]}
+
+            th = threading.Thread(target=run_leg, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("FR_BENCH_NODE_LEG_TIMEOUT", "120")))
+            node_leg_stuck = th.is_alive()
+            fr_node_obj = {"error": "the fr_node leg did not finish within its deadline (FR_BENCH_NODE_LEG_TIMEOUT)"} if node_leg_stuck \
+                else box.get("obj", {"error": "the fr_node leg ended without a result"})
         dist.barrier(group=host_group)
 
     if rank == 0:
@@ -960,6 +975,11 @@ def main() -> None:
                                        "render contexts); the kernels are VALU-bound, see the N = 1 line for roofline_valu"}
         print(json.dumps(out), flush=True)
 
+    if node_leg_stuck:
+        # a thread of this process is stuck inside the informational leg: the line is out, leave without the destructors
+        sys.stdout.flush()
+        sys.stderr.write("bench.py: the fr_node leg is stuck; exiting without teardown\n")
+        os._exit(0)
     if world > 1:
         for c in ctxs[1:]:
             c.close()
