@@ -9,6 +9,9 @@ import fractalrenderer_amd as fr
 from bench import WORKLOADS
 names = sys.argv[1:] or ["c2", "c3", "c5"]
 ctxs = [fr.Renderer(0) for _ in range(4)]
+for kv in filter(None, os.environ.get("FR_SPLIT_OPTS", "").split(",")):      # e.g. FR_SPLIT_OPTS=periodicity=-1
+    for c in ctxs: c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+STRIPS = int(os.environ.get("FR_SPLIT_STRIPS", "0"))                           # rows per strip: interleaved strips instead of bands
 streams = [torch.cuda.Stream() for _ in range(4)]
 for name in names:
     w = WORKLOADS[name]; W, H = w["W"], w["H"]
@@ -26,8 +29,12 @@ for name in names:
         for k in range(K):
             s = streams[k]
             s.wait_event(fork)
-            ctxs[k].render(st, W, H, rgba=out[k * R:(k + 1) * R], shard=fr.Shard(k, K, R) if K > 1 else None,
-                           sync=False, stream=s.cuda_stream, **kw)
+            if STRIPS and K > 1:             # whole-frame planes are not exposed to Python: packed part buffers (not compared)
+                sh = fr.Shard(k, K, STRIPS)
+                ctxs[k].render(st, W, H, rgba=out[k * R:k * R + sh.rows(H)], shard=sh, sync=False, stream=s.cuda_stream, **kw)
+            else:
+                ctxs[k].render(st, W, H, rgba=out[k * R:(k + 1) * R], shard=fr.Shard(k, K, R) if K > 1 else None,
+                               sync=False, stream=s.cuda_stream, **kw)
             e = torch.cuda.Event(); e.record(s); joins.append(e)
         for e in joins: main.wait_event(e)
 
