@@ -1360,6 +1360,38 @@ def test_rccl_plugin_next_to_torch(fr):
     assert any("librccl" in m for m in maps), maps
 
 
+def test_bench_node_host_and_default_lines(fr):
+    """bench.py keeps its contract on the C-ABI host: `--host node` (ONE process, fr_node: every gather x mode pair the box
+    allows, here with two parts on this card and the one-rank RCCL loopback with one) prints ONE JSON line with the
+    contract's keys, a `node` object whose runs are all verified against fr_render -- and the default command's line still
+    carries roofline + roofline_valu (cpu_baseline switched off here for time)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def line(*flags):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--steps", "4", "--warmup", "1", *flags],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        return json.loads(lines[0])
+
+    for parts in (1, 2):
+        d = line("--host", "node", "--gpus", "1", "--node-parts", str(parts))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline"):
+            assert k in d, k
+        assert d["host"] == "node" and d["value"] > 0 and d["exchange_verified"] is True
+        runs = d["node"]["runs"]
+        assert all("error" not in r and r["exchange_verified"] for r in runs), runs
+        assert {r["mode"] for r in runs} == {"sequence", "frame"}
+        assert any(r["gather"] == "rccl" for r in runs) == (parts == 1)          # the loopback needs a node of one part
+    d = line("--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and "roofline" in d and "roofline_valu" in d and d["roofline"]["kernel_ms"] > 0
+
+
 @pytest.mark.parametrize("n,slots,lanes", [(1, 2, 2), (4, 3, 2), (8, 8, 4)])
 def test_node_frames_in_flight_device_planes(fr, renderer, n, slots, lanes):
     """fr_node_submit / fr_node_wait_frame with device planes: 12 different frames, up to `slots` in flight on `lanes` render
