@@ -76,6 +76,15 @@ class fr_anim_info(C.Structure):
                 ("export_width", C.c_int32), ("export_height", C.c_int32), ("keyframe_count", C.c_int32)]
 
 
+FR_FRAME_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int32, C.c_void_p)
+
+
+class fr_anim_render_options(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("first_frame", C.c_int32), ("frame_count", C.c_int32),
+                ("frame_step", C.c_int32), ("max_iterations_override", C.c_int32), ("fractal_type_override", C.c_int32),
+                ("on_frame_complete", FR_FRAME_CALLBACK), ("user", C.c_void_p)]
+
+
 class fr_keyframe(C.Structure):
     _fields_ = [("time", C.c_float), ("interp_type", C.c_int32), ("state", fr_params)]
 
@@ -108,6 +117,7 @@ SIGNATURES = {
     "fr_node_submit": (C.c_int, [C.c_void_p, _P(fr_params), C.c_uint32, C.c_uint32, C.c_int, _P(fr_output), _P(C.c_uint64)]),
     "fr_node_wait_frame": (C.c_int, [C.c_void_p, C.c_uint64]),
     "fr_node_in_flight": (C.c_int, [C.c_void_p]),
+    "fr_node_render_animation": (C.c_int, [C.c_void_p, C.c_void_p, _P(fr_params), C.c_void_p, C.c_char_p, _P(C.c_int32)]),
     "fr_node_last_gather": (C.c_int, [C.c_void_p]),
     "fr_node_last_kernel_ms": (C.c_float, [C.c_void_p, C.c_int]),
     "fr_ctx_last_kernel_ms": (C.c_float, [C.c_void_p]),

@@ -32,9 +32,11 @@
 #include <hip/hip_runtime_api.h>
 
 #include <dlfcn.h>
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <atomic>
 #include <chrono>
@@ -858,6 +860,231 @@ extern "C" int fr_node_render(fr_node* nd, const fr_params* p, uint32_t W, uint3
     const int st = fr_node_submit(nd, p, W, H, root, out, &t);
     if (st != FR_OK) return st;
     return fr_node_wait_frame(nd, t);
+}
+
+/* ---- AnimationRenderer::start_render over the GPUs of a node ------------------------------------------------------------
+ * src/animation_renderer.cpp:26-152 is a loop: time = frame / float(fps) (:80), state = interpolate(time) (:83),
+ * "<folder>/frame_%06d.png" (:86-88), render_frame -> the RenderFrameCallback (:216), on_frame_complete (:123-125),
+ * cancel_requested (:76).  Here every frame is cut over the node's parts (fr_node_submit, roots rotating, up to "slots"
+ * frames in flight), and what the reference's callback body does after its dispatch (src/vk_engine.cpp:1266-1381: readback,
+ * half -> float, second ACES + gamma, u8, flip, PNG) runs where the frame was assembled: fr_export_rgb8 on the root's device,
+ * 3 bytes per pixel come back, and a writer thread deflates (fr_write_png, band-parallel) while the devices render the next
+ * frames.  The files are byte-identical to fr_render_frame_png's. */
+namespace {
+
+int make_dirs(const char* path)                           /* std::filesystem::create_directories, :58-69 */
+{
+    char buf[4096];
+    const size_t n = strlen(path);
+    if (n == 0 || n >= sizeof buf) return fr_set_error(FR_ERR_INVALID_ARG, "output folder: empty or too long");
+    memcpy(buf, path, n + 1);
+    for (size_t i = 1; i <= n; ++i) {
+        if (buf[i] != '/' && buf[i] != 0) continue;
+        const char keep = buf[i];
+        buf[i] = 0;
+        if (mkdir(buf, 0777) != 0 && errno != EEXIST) return fr_set_error(FR_ERR_IO, "Failed to create output directory %s: %s", buf, strerror(errno));
+        buf[i] = keep;
+    }
+    struct stat sb;
+    if (stat(path, &sb) != 0 || !S_ISDIR(sb.st_mode)) return fr_set_error(FR_ERR_IO, "Failed to create output directory %s", path);
+    return FR_OK;
+}
+
+struct AnimJob { int32_t frame; uint8_t* rgb8; };
+
+struct AnimWriter {                                       /* one thread: PNG files, in submission order */
+    std::thread thread;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<AnimJob> jobs;
+    std::deque<uint8_t*> free_bufs;
+    std::deque<int32_t> written;                          /* frames whose files are complete, for the caller's callbacks */
+    bool quit = false;
+    int status = FR_OK;
+    char err[512] = {0};
+    const char* folder = nullptr;
+    uint32_t W = 0, H = 0;
+
+    void loop()
+    {
+        for (;;) {
+            AnimJob j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return !jobs.empty() || quit; });
+                if (jobs.empty()) return;
+                j = jobs.front();
+                jobs.pop_front();
+            }
+            char path[4096];
+            int st = fr_frame_path(folder, j.frame, path, sizeof path);
+            if (st == FR_OK) st = fr_write_png(path, W, H, 8, j.rgb8, nullptr, 0, 0);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (st != FR_OK && status == FR_OK) { status = st; snprintf(err, sizeof err, "frame %d: %s", j.frame, fr_last_error()); }
+                if (st == FR_OK) written.push_back(j.frame);
+                free_bufs.push_back(j.rgb8);
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int fr_node_render_animation(fr_node* nd, const fr_anim* anim, const fr_params* base, const fr_anim_render_options* opt,
+                                        const char* output_folder, int32_t* frames_written)
+{
+    if (frames_written) *frames_written = 0;
+    if (!nd || !anim || !base || !output_folder) return fr_set_error(FR_ERR_INVALID_ARG, "fr_node_render_animation: NULL argument");
+    if (frames_in_flight(nd)) return fr_set_error(FR_ERR_INVALID_ARG, "fr_node_render_animation: frames are in flight (fr_node_wait first)");
+    fr_anim_info info;
+    int st = fr_anim_get_info(anim, &info);
+    if (st != FR_OK) return st;
+    if (info.keyframe_count < 2) return fr_set_error(FR_ERR_INVALID_ARG, "Need at least 2 keyframes to render");       /* :35-42 */
+    fr_anim_render_options none;
+    memset(&none, 0, sizeof none);
+    const fr_anim_render_options o = opt ? *opt : none;
+    const int32_t total = fr_anim_frame_count(anim);                                                                   /* :48 */
+    const uint32_t W = (uint32_t)(o.width > 0 ? o.width : info.export_width), H = (uint32_t)(o.height > 0 ? o.height : info.export_height);
+    const int32_t step = o.frame_step > 1 ? o.frame_step : 1;
+    const int32_t first = o.first_frame > 0 ? o.first_frame : 0;
+    int32_t last = total;                                 /* exclusive */
+    if (o.frame_count > 0 && (int64_t)first + (int64_t)o.frame_count * step < (int64_t)total) last = first + o.frame_count * step;
+    {   /* the first frame's parameters must be renderable before anything is created */
+        fr_params p0;
+        st = fr_anim_state_at(anim, fr_anim_frame_time(anim, first < total ? first : 0), base, &p0);
+        if (st == FR_OK) st = fr_params_validate(&p0, W, H);
+        if (st != FR_OK) return st;
+    }
+    st = make_dirs(output_folder);
+    if (st != FR_OK) return st;
+    if (first >= last) return FR_OK;
+
+    DeviceGuard guard;
+    const int n = nd->n, S = nd->slots;
+    const size_t npx = (size_t)W * H;
+    /* per plane set (as many as frame slots) and root: the frame's colour plane and its RGB8 on the root's device, on first use */
+    float* d_rgba[kMaxSlots][kMaxParts] = {{nullptr}};
+    uint8_t* d_rgb8[kMaxSlots][kMaxParts] = {{nullptr}};
+    hipStream_t xs[kMaxParts] = {nullptr};                /* export + copy-back stream per root */
+    std::vector<uint8_t*> host_bufs;
+    AnimWriter wr;
+    wr.folder = output_folder; wr.W = W; wr.H = H;
+    struct Pending { uint64_t ticket; int32_t frame; int root, set; };
+    std::deque<Pending> pending;
+    int rc = FR_OK;
+    char keep[512] = {0};
+    int32_t done = 0;
+    bool cancelled = false;
+    auto fail = [&](int s) { if (rc == FR_OK) { rc = s; snprintf(keep, sizeof keep, "%s", fr_last_error()); } };
+    auto hip_fail = [&](const char* what, hipError_t e) { if (rc == FR_OK) { rc = FR_ERR_HIP; snprintf(keep, sizeof keep, "%s failed: %s", what, hipGetErrorString(e)); } };
+
+    for (int k = 0; k < S + 1 && rc == FR_OK; ++k) {      /* pinned RGB8 frames: one being filled, S at the writer */
+        uint8_t* b = nullptr;
+        const hipError_t e = hipHostMalloc((void**)&b, npx * 3, hipHostMallocDefault);
+        if (e != hipSuccess) { hip_fail("hipHostMalloc", e); break; }
+        host_bufs.push_back(b);
+        wr.free_bufs.push_back(b);
+    }
+    if (rc == FR_OK) wr.thread = std::thread([&wr] { wr.loop(); });
+
+    /* the caller's callbacks, on the caller's thread, for frames whose files are complete */
+    auto deliver = [&]() {
+        for (;;) {
+            int32_t f;
+            {
+                std::lock_guard<std::mutex> lk(wr.m);
+                if (wr.status != FR_OK && rc == FR_OK) { rc = wr.status; snprintf(keep, sizeof keep, "%s", wr.err); }
+                if (wr.written.empty()) return;
+                f = wr.written.front();
+                wr.written.pop_front();
+            }
+            ++done;
+            if (o.on_frame_complete && o.on_frame_complete(f, total, o.user) != 0) cancelled = true;      /* :123-125, :76 */
+        }
+    };
+    /* the oldest frame in flight: wait, export where it lives, copy 3 B/pixel back, hand it to the writer */
+    auto finish_oldest = [&]() {
+        const Pending f = pending.front();
+        pending.pop_front();
+        int s = fr_node_wait_frame(nd, f.ticket);
+        if (s != FR_OK) { fail(s); return; }
+        if (rc != FR_OK) return;
+        uint8_t* hb = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(wr.m);
+            wr.cv.wait(lk, [&] { return !wr.free_bufs.empty(); });
+            hb = wr.free_bufs.front();
+            wr.free_bufs.pop_front();
+        }
+        hipError_t e = hipSetDevice(nd->devices[f.root]);
+        if (e == hipSuccess) {
+            s = fr_export_rgb8_async(nd->ctx[f.root][0], d_rgba[f.set][f.root], W, H, d_rgb8[f.set][f.root], 1, (void*)xs[f.root]);
+            if (s != FR_OK) fail(s);
+            else {
+                e = hipMemcpyAsync(hb, d_rgb8[f.set][f.root], npx * 3, hipMemcpyDeviceToHost, xs[f.root]);
+                if (e == hipSuccess) e = hipStreamSynchronize(xs[f.root]);
+            }
+        }
+        if (e != hipSuccess) hip_fail("readback", e);
+        {
+            std::lock_guard<std::mutex> lk(wr.m);
+            if (rc == FR_OK) wr.jobs.push_back({f.frame, hb});
+            else wr.free_bufs.push_back(hb);
+        }
+        wr.cv.notify_all();
+    };
+
+    int submitted = 0;
+    for (int32_t frame = first; frame < last && rc == FR_OK && !cancelled; frame += step) {
+        const float time = fr_anim_frame_time(anim, frame);                                                          /* :80 */
+        fr_params p;
+        st = fr_anim_state_at(anim, time, base, &p);                                                                  /* :83 */
+        if (st != FR_OK) { fail(st); break; }
+        if (o.fractal_type_override) p.fractal_type = o.fractal_type_override - 1;
+        if (o.max_iterations_override > 0) p.max_iterations = o.max_iterations_override;
+        if (p.fractal_type != FR_FRACTAL_DEEP_ZOOM) p.flags |= FR_FLAG_POST_CHAIN;     /* what the rgba16f storage image holds */
+        const int set = submitted % S, root = submitted % n;
+        while ((int)pending.size() >= S && rc == FR_OK) finish_oldest();             /* that plane set's previous frame goes out first */
+        if (rc != FR_OK) break;
+        if (!d_rgba[set][root]) {
+            hipError_t e = hipSetDevice(nd->devices[root]);
+            if (e == hipSuccess) e = hipMalloc((void**)&d_rgba[set][root], npx * 16);
+            if (e == hipSuccess) e = hipMalloc((void**)&d_rgb8[set][root], npx * 3);
+            if (e == hipSuccess && !xs[root]) e = hipStreamCreateWithFlags(&xs[root], hipStreamNonBlocking);
+            if (e != hipSuccess) { hip_fail("hipMalloc", e); break; }
+        }
+        const fr_output out = {d_rgba[set][root], nullptr, nullptr, FR_MEM_DEVICE, FR_LAYOUT_PACKED};
+        uint64_t t = 0;
+        st = fr_node_submit(nd, &p, W, H, root, &out, &t);
+        if (st != FR_OK) { fail(st); break; }
+        pending.push_back({t, frame, root, set});
+        ++submitted;
+        deliver();
+    }
+    while (!pending.empty()) {
+        if (rc == FR_OK && !cancelled) finish_oldest();
+        else { (void)fr_node_wait_frame(nd, pending.front().ticket); pending.pop_front(); }
+    }
+    if (wr.thread.joinable()) {
+        { std::lock_guard<std::mutex> lk(wr.m); wr.quit = true; }
+        wr.cv.notify_all();
+        wr.thread.join();
+    }
+    deliver();
+    for (int s2 = 0; s2 < kMaxSlots; ++s2)
+        for (int k = 0; k < n; ++k)
+            if (d_rgba[s2][k] || d_rgb8[s2][k]) {
+                (void)hipSetDevice(nd->devices[k]);
+                if (d_rgba[s2][k]) (void)hipFree(d_rgba[s2][k]);
+                if (d_rgb8[s2][k]) (void)hipFree(d_rgb8[s2][k]);
+            }
+    for (int k = 0; k < n; ++k)
+        if (xs[k]) { (void)hipSetDevice(nd->devices[k]); (void)hipStreamDestroy(xs[k]); }
+    for (uint8_t* b : host_bufs) (void)hipHostFree(b);
+    if (frames_written) *frames_written = done;
+    return rc == FR_OK ? FR_OK : fr_set_error(rc, "%s", keep);
 }
 
 /* Internal (fr_tuning.h): drives the RCCL leg on ONE device -- loads the plugin, creates a one-rank communicator on

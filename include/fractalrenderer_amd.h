@@ -323,6 +323,7 @@ int fr_ctx_synchronize(fr_ctx* ctx);
  *   1 = always the planes asked for), "slots" (1..8 frames in flight, 0 = automatic: 2), "lanes" (1..4 render contexts
  *   per part, created on first use, 0 = automatic: 2), and every fr_ctx_set_option name, applied to all contexts. */
 typedef struct fr_node fr_node;
+typedef struct fr_anim fr_anim;   /* (.franim animations, below) */
 typedef enum fr_gather { FR_GATHER_AUTO = 0, FR_GATHER_PEER = 1, FR_GATHER_RCCL = 2 } fr_gather;
 #define FR_ROOT_ROTATE (-1)           /* fr_node_submit / fr_node_render: root = (ticket - 1) % n; FR_MEM_HOST planes */
 
@@ -342,6 +343,29 @@ int  fr_node_in_flight(const fr_node* node);
 int  fr_node_last_gather(const fr_node* node);
 /* device time of part `part`'s kernels of the most recently submitted frame (fr_ctx_last_kernel_ms of its context) */
 float fr_node_last_kernel_ms(fr_node* node, int part);
+
+/* AnimationRenderer::start_render (src/animation_renderer.cpp:26-152) over the GPUs of a node: for frame = first, first +
+ * step, ...: time = frame / float(target_fps) (:80), state = interpolate(time) (:83; fr_anim_state_at with `base`, whose
+ * fractal_type / precision / flags are not animated), the frame rendered over the node's parts with the shader's post chain
+ * (fr_node_submit, roots rotating, up to "slots" frames in flight), and the RenderFrameCallback's tail
+ * (src/vk_engine.cpp:1266-1381: readback, second ACES + gamma, u8, flip, PNG) done where the frame was assembled -- the
+ * 8-bit export on the root's device, 3 bytes per pixel back, "<folder>/frame_%06d.png" (:86-88) written by a thread of
+ * its own while the devices render the next frames.  Files are byte-identical to fr_render_frame_png's.  Fewer than 2
+ * keyframes: FR_ERR_INVALID_ARG ("Need at least 2 keyframes to render", :35-42).  on_frame_complete (:123-125) is called on
+ * the CALLER's thread for every frame whose file is complete, in order; returning non-zero requests cancellation
+ * (cancel_requested, :76): no further frame is started, the call returns FR_OK with *frames_written short of the plan. */
+typedef int (*fr_frame_callback)(int32_t frame, int32_t total_frames, void* user);
+typedef struct fr_anim_render_options {
+    int32_t width, height;                /* 0: the animation's export_width / export_height                        */
+    int32_t first_frame, frame_count;     /* frame_count 0: to the end (total = int(duration * target_fps), :48)     */
+    int32_t frame_step;                   /* every n-th frame (a sub-sampled sweep); 0 / 1: every frame              */
+    int32_t max_iterations_override;      /* 0: the keyframes'                                                       */
+    int32_t fractal_type_override;        /* 0: base's; else fr_fractal_type + 1 (the engine's current_fractal_type) */
+    fr_frame_callback on_frame_complete;  /* may be NULL                                                             */
+    void* user;
+} fr_anim_render_options;
+int  fr_node_render_animation(fr_node* node, const fr_anim* anim, const fr_params* base, const fr_anim_render_options* options,
+                              const char* output_folder, int32_t* frames_written);
 
 /* ---- recolour from the smooth-count plane (multi-GPU exchange payload) ------------------------
  * New design, no reference counterpart (the reference is single-GPU): for the plain colourings the

@@ -11,6 +11,9 @@
  *                                (every gather), a whole frame through the RCCL calls of a one-rank communicator
  *                                ("rccl_loopback"), a part that fails between the barrier and its sends (communicators
  *                                aborted, the wait returns an error, the node carries on)
+ *   node_client anim <folder>    fr_node_render_animation (AnimationRenderer::start_render over a node): a 3-keyframe animation built
+ *                                with fr_anim_add_keyframe, every 10th frame on devices = {0,0}, each PNG byte for byte the one
+ *                                fr_render_frame_png writes; the frame callback, in order
  *   node_client node <n>         n DISTINCT devices 0..n-1 (needs an n-GPU box): RCCL gather (both payloads) and in-place
  *                                peer stores, every root, bitwise against fr_render on device 0; then a pipelined sequence
  *                                with rotating roots through both gathers
@@ -266,6 +269,64 @@ static int failsafe_part(void)
     return 0;
 }
 
+/* ---- the reference's animation loop, from C ------------------------------------------------------------------------------ */
+static int seen_frames[64], n_seen = 0;
+static int on_frame(int32_t frame, int32_t total, void* user) { (void)total; (void)user; if (n_seen < 64) seen_frames[n_seen++] = frame; return 0; }
+
+static int same_file(const char* a, const char* b)
+{
+    FILE* fa = fopen(a, "rb"); FILE* fb = fopen(b, "rb");
+    if (!fa || !fb) { if (fa) fclose(fa); if (fb) fclose(fb); return 0; }
+    int same = 1, ca, cb;
+    do { ca = fgetc(fa); cb = fgetc(fb); if (ca != cb) same = 0; } while (same && ca != EOF);
+    fclose(fa); fclose(fb);
+    return same;
+}
+
+static int anim_part(const char* folder)
+{
+    fr_anim* anim = NULL;
+    CHECK(fr_anim_create(&anim) == FR_OK);
+    fr_params k;
+    fr_params_default(&k);
+    k.max_iterations = 300;
+    CHECK(fr_anim_add_keyframe(anim, 0.0f, &k, FR_INTERP_LINEAR) == FR_OK);
+    k.center_x = -0.743643887037151; k.center_y = 0.13182590420533; k.zoom = 0.05; k.max_iterations = 900; k.palette_mode = 3;
+    CHECK(fr_anim_add_keyframe(anim, 1.0f, &k, FR_INTERP_EASE_IN_OUT) == FR_OK);
+    k.zoom = 0.002; k.max_iterations = 1500;
+    CHECK(fr_anim_add_keyframe(anim, 2.0f, &k, FR_INTERP_EXPONENTIAL) == FR_OK);
+    fr_params base;
+    fr_params_default(&base);
+    base.precision = FR_PRECISION_F64;
+    int devs[2] = {0, 0};
+    fr_node* node = NULL;
+    CHECK(fr_node_create(devs, 2, &node) == FR_OK);
+    fr_anim_render_options o;
+    memset(&o, 0, sizeof o);
+    o.width = 240; o.height = 160; o.frame_step = 10; o.on_frame_complete = on_frame;
+    int32_t wrote = 0;
+    const int32_t total = fr_anim_frame_count(anim);
+    CHECK(total > 20);
+    CHECK(fr_node_render_animation(node, anim, &base, &o, folder, &wrote) == FR_OK);
+    CHECK(wrote == (total + 9) / 10 && n_seen == wrote);
+    fr_ctx* ctx = NULL;
+    CHECK(fr_ctx_create(0, &ctx) == FR_OK);
+    for (int i = 0; i < wrote; ++i) {
+        CHECK(seen_frames[i] == 10 * i);
+        fr_params p;
+        CHECK(fr_anim_state_at(anim, fr_anim_frame_time(anim, 10 * i), &base, &p) == FR_OK);
+        char got[4096], want[4096];
+        CHECK(fr_frame_path(folder, 10 * i, got, sizeof got) == FR_OK);
+        snprintf(want, sizeof want, "%s/reference_%d.png", folder, i);
+        CHECK(fr_render_frame_png(ctx, &p, 240, 160, want) == FR_OK);
+        CHECK(same_file(got, want));
+    }
+    fr_ctx_destroy(ctx);
+    fr_node_destroy(node);
+    fr_anim_free(anim);
+    return 0;
+}
+
 static int rccl_part(void)
 {
     int version = 0;
@@ -301,8 +362,9 @@ int main(int argc, char** argv)
     if (argc >= 2 && strcmp(argv[1], "lanes") == 0) { const int r = lanes_part(); if (!r) puts("lanes ok"); return r; }
     if (argc >= 2 && strcmp(argv[1], "seq") == 0) { const int r = seq_part(); if (!r) puts("seq ok"); return r; }
     if (argc >= 2 && strcmp(argv[1], "failsafe") == 0) { const int r = failsafe_part(); if (!r) puts("failsafe ok"); return r; }
+    if (argc >= 3 && strcmp(argv[1], "anim") == 0) { const int r = anim_part(argv[2]); if (!r) puts("anim ok"); return r; }
     if (argc >= 2 && strcmp(argv[1], "rccl") == 0) { const int r = rccl_part(); if (!r) puts("rccl ok"); return r; }
     if (argc >= 3 && strcmp(argv[1], "node") == 0) { const int r = node_part(atoi(argv[2])); if (!r) puts("node ok"); return r; }
-    fprintf(stderr, "usage: node_client lanes | seq | failsafe | rccl | node <n>\n");
+    fprintf(stderr, "usage: node_client lanes | seq | failsafe | anim <folder> | rccl | node <n>\n");
     return 2;
 }

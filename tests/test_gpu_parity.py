@@ -1173,6 +1173,46 @@ def test_distributed_animation_export_matches_single_gpu_pngs(fr, renderer, tmp_
         assert open(ref_path, "rb").read() == open(os.path.join(out_dir, "frame_%06d.png" % f), "rb").read(), f
 
 
+@pytest.mark.parametrize("n,slots", [(1, 2), (3, 4)])
+def test_node_render_animation_matches_single_gpu_pngs(fr, renderer, tmp_path, n, slots):
+    """fr_node_render_animation: AnimationRenderer::start_render over the parts of a node, from C -- the reference's own
+    .franim, every 300th frame of its 2400, frames in flight, roots rotating, the 8-bit export where the frame was assembled,
+    a writer thread for the PNGs.  Every file byte-identical to the single-GPU RenderFrameCallback body's
+    (fr_render_frame_png); the callback sees every frame in order and can cancel; fewer than 2 keyframes are refused."""
+    anim = fr.AnimationSystem()
+    assert anim.load_from_file(os.path.join(os.path.dirname(__file__), "golden", "reference_sample.franim"))
+    out_dir = str(tmp_path / "nested" / "out")                      # created by the call (create_directories)
+    seen = []
+    with fr.Node([0] * n) as node:
+        node.set_option("slots", slots)
+        wrote = node.render_animation(anim, out_dir, width=200, height=136, frame_step=300, precision=fr.Precision.F32,
+                                      on_frame_complete=lambda f, t: seen.append((f, t)) and False)
+        frames = list(range(0, 2400, 300))
+        assert wrote == len(frames) and seen == [(f, 2400) for f in frames]
+        assert sorted(os.listdir(out_dir)) == ["frame_%06d.png" % f for f in frames]
+        for f in frames:
+            ref_path = str(tmp_path / ("ref_%06d.png" % f))
+            assert renderer.render_frame(anim.interpolate(anim.frame_time(f)), 200, 136, ref_path)
+            assert open(ref_path, "rb").read() == open(os.path.join(out_dir, "frame_%06d.png" % f), "rb").read(), f
+        # a window of the sequence, fp64, with an iteration override; cancelled by the callback after its third frame
+        out2 = str(tmp_path / "win")
+        count = []
+        wrote = node.render_animation(anim, out2, width=96, height=64, first_frame=1000, frame_count=40, frame_step=2,
+                                      precision=fr.Precision.F64, max_iterations=700,
+                                      on_frame_complete=lambda f, t: count.append(f) or len(count) >= 3)
+        assert 3 <= wrote < 20 and count[:3] == [1000, 1002, 1004] and node.in_flight() == 0
+        st = anim.interpolate(anim.frame_time(1002))
+        st.max_iterations = 700
+        ref_path = str(tmp_path / "ref_win.png")
+        assert renderer.render_frame(st, 96, 64, ref_path, precision=fr.Precision.F64)
+        assert open(ref_path, "rb").read() == open(os.path.join(out2, "frame_001002.png"), "rb").read()
+        one = fr.AnimationSystem()
+        one.add_keyframe(0.0, fr.FractalState())
+        with pytest.raises(fr.FractalRendererError) as e:
+            node.render_animation(one, str(tmp_path / "none"))
+        assert "at least 2 keyframes" in str(e.value) and not os.path.exists(str(tmp_path / "none"))
+
+
 def test_randomised_views_match_the_oracle(fr, renderer, oracle):
     """Seeded sweep over the parameter space (fractal, precision, view, iteration budget, bailout, palette,
     frame shape, row-strip shard): escape indices bit-exact, nu and colour within the stated bars.  Views are
@@ -1317,6 +1357,16 @@ def test_plain_c_node_client_frames_in_flight(fr, tmp_path):
     exe = build_c_client(tmp_path, "node_client.c")
     out = subprocess.run([exe, "seq"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip() == "seq ok", out.stderr + out.stdout
+
+
+def test_plain_c_node_client_animation(fr, tmp_path):
+    """`anim`: fr_node_render_animation from plain C -- keyframes added through the ABI, every 10th frame over two parts,
+    the callback in order, every PNG byte for byte fr_render_frame_png's."""
+    import subprocess
+    from test_host import build_c_client
+    exe = build_c_client(tmp_path, "node_client.c")
+    out = subprocess.run([exe, "anim", str(tmp_path / "frames" / "a")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "anim ok", out.stderr + out.stdout
 
 
 def test_plain_c_node_client_gather_failure_paths(fr, tmp_path):
