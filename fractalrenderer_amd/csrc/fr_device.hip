@@ -727,12 +727,17 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t
         if (big > auto_first) auto_first = big;
     }
     const int first = c->tune_stage_first ? (int)c->tune_stage_first : auto_first;
-    /* The second pass pays off where orbits are long: below max_iter ~768 (~384 on frames above 4K) ONE pass whose
-     * waves stop at their home shard is faster -- 1080p at max_iter 256: 0.061 ms against 0.109 ms, the Seahorse view
-     * at 4096^2 / 256: 0.69 against 1.02 ms (nearly every pixel survives the tile pass there and is handled twice);
-     * above it the two passes win by up to 35 % (profiles/r01_staging_crossover.txt).  An explicit "staging" or
-     * "stage_first" stages whenever there is room for two budgets. */
-    const int auto_min = npx > ((size_t)1 << 23) ? 384 : 768;
+    /* The second pass pays off where orbits are long.  Rounds 1-3: below max_iter ~768 (~384 on frames above 4K) ONE pass
+     * whose waves stop at their home shard was faster -- 1080p at max_iter 256: 0.061 ms against 0.109 ms -- and above it
+     * the two passes won by up to 35 % (profiles/r01_staging_crossover.txt).  Round 4's lane pool (deferred escapes) moved
+     * the crossover down where escapes are spread out (profiles/r04_staging_crossover.txt, 168 cells): a Julia set wins
+     * with two passes from max_iter 256 (-5 to -12 %; 384: -15 to -30 %; 512: -23 to -36 %), an fp64 Mandelbrot view
+     * from 512 at every size up to 4K (-6 to -13 %; 384 on frames above 2^23 pixels as before: the default view loses 5-9 %
+     * there, the Seahorse view wins 15-28 %), an fp32 one stays at 768 (512 above 2^23 pixels, where 384 lost 7-11 %).
+     * An explicit "staging" or "stage_first" stages whenever there is room for two budgets. */
+    const bool big = npx > ((size_t)1 << 23);
+    const int auto_min = p->fractal_type == FR_FRACTAL_JULIA ? 256
+                       : (p->precision == FR_PRECISION_F64 ? (big ? 384 : 512) : (big ? 512 : 768));
     const bool forced = c->tune_staging != 0 || c->tune_stage_first != 0;
     if (allow && (forced ? max_iter >= 2 * first : max_iter >= auto_min)) {
         int b = first - first % kFastBlock;                      /* the budget is a multiple of the unchecked block */

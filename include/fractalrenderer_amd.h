@@ -246,8 +246,9 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                   is quoted on the reference's iteration count.
  *   "staging"       0 = automatic, 1 = single pass (every sample runs to max_iter in the tile kernel), 3 = tile pass for
  *                   the first b0 iterations + ONE lane-pool pass over the compacted survivors, whatever max_iter is.
- *                   Automatic: 3 where it applies (no SSAA, no trap / stripe effects) and pays off -- max_iterations
- *                   >= 768, or >= 384 on frames above 2^23 pixels (profiles/r01_staging_crossover.txt).
+ *                   Automatic: 3 where it applies (no SSAA, no trap / stripe effects) and pays off -- a Julia set from
+ *                   max_iterations 256, fp64 from 512 (384 on frames above 2^23 pixels), fp32 from 768 (512)
+ *                   (profiles/r04_staging_crossover.txt).
  *   "shards"        8 or 64: shards of the work queue (each has ONE head word that its waves update with returning
  *                   atomics, ~15 ns apart).  Automatic: 64 (8 per XCD) for launches whose waves stop at their home shards
  *                   on grids of >= 512 workgroups, else 8.
