@@ -65,6 +65,10 @@ struct fr_ctx {
     void* coord_buf;            /* lean tile pass: W + H coordinates of the frame being rendered (prepare_kernel) */
     size_t coord_bytes;
     uint32_t tune_tile_kernel;  /* 0 = automatic (the lean tile kernel where it applies), 1 = the general tile_kernel */
+    uint32_t tune_ssaa;         /* SSAA: 0 = automatic, 1 = the sample loop of the general tile kernel, 2 = staged (sample grid
+                                 * through tile pass + lane pool, then ssaa_reduce_kernel) wherever it applies */
+    void* ssaa_buf;             /* staged SSAA: the sample planes (colour [+ nu] [+ iter]), grow-only */
+    size_t ssaa_bytes;
     uint32_t tune_shards;       /* 0 = automatic, 8 or 64: queue shards / stream regions of a render */
     uint32_t tune_regions;      /* 0 = automatic (= shards), 8 or 64: regions of the survivor streams */
     uint32_t tune_tile_pixels;  /* lean tile kernel: sub-tiles (pixels per lane) per trip, 0 = automatic (2), 1 or 2 */
@@ -159,6 +163,7 @@ extern "C" void fr_ctx_destroy(fr_ctx* c)
     if (c->log2_tab) (void)hipFree(c->log2_tab);
     if (c->export8_thr) (void)hipFree(c->export8_thr);
     if (c->coord_buf) (void)hipFree(c->coord_buf);
+    if (c->ssaa_buf) (void)hipFree(c->ssaa_buf);
     if (c->stream_buf) (void)hipFree(c->stream_buf);
     if (c->frame_buf) (void)hipFree(c->frame_buf);
     if (c->orbit_host) (void)hipHostFree(c->orbit_host);
@@ -255,6 +260,9 @@ extern "C" int fr_ctx_set_tuning(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "tile_pixels")) {
         if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "tile_pixels must be 0 (automatic), 1 or 2");
         c->tune_tile_pixels = (uint32_t)value;
+    } else if (!strcmp(name, "ssaa")) {
+        if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "ssaa must be 0 (automatic), 1 (sample loop of the general tile kernel) or 2 (staged)");
+        c->tune_ssaa = (uint32_t)value;
     } else if (!strcmp(name, "pool_items_per_wg")) {
         if (value < 0 || value > 4096) return fr_set_error(FR_ERR_INVALID_ARG, "pool_items_per_wg must be in [0,4096]");
         c->tune_pool_items_per_wg = (uint32_t)value;
@@ -706,6 +714,12 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
  * must meet again to be averaged), the effects variants (accumulators along the whole orbit), short max_iter.  Returns
  * the number of passes; bounds[k] = upper iteration bound of pass k.  (Block stream passes with x4 budgets and a fused
  * one-launch schedule were built and measured slower everywhere: DESIGN.md section 7.) */
+static int staging_threshold(const fr_params* p, size_t npx)
+{
+    const bool big = npx > ((size_t)1 << 23);
+    return p->fractal_type == FR_FRACTAL_JULIA ? 256 : (p->precision == FR_PRECISION_F64 ? (big ? 384 : 512) : (big ? 512 : 768));
+}
+
 static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t npx, bool pool_runs_everything, int bounds[kMaxStages])
 {
     const int max_iter = p->max_iterations;
@@ -735,9 +749,7 @@ static int plan_stages(const fr_ctx* c, const fr_params* p, bool effects, size_t
      * from 512 at every size up to 4K (-6 to -13 %; 384 on frames above 2^23 pixels as before: the default view loses 5-9 %
      * there, the Seahorse view wins 15-28 %), an fp32 one stays at 768 (512 above 2^23 pixels, where 384 lost 7-11 %).
      * An explicit "staging" or "stage_first" stages whenever there is room for two budgets. */
-    const bool big = npx > ((size_t)1 << 23);
-    const int auto_min = p->fractal_type == FR_FRACTAL_JULIA ? 256
-                       : (p->precision == FR_PRECISION_F64 ? (big ? 384 : 512) : (big ? 512 : 768));
+    const int auto_min = staging_threshold(p, npx);
     const bool forced = c->tune_staging != 0 || c->tune_stage_first != 0;
     if (allow && (forced ? max_iter >= 2 * first : max_iter >= auto_min)) {
         int b = first - first % kFastBlock;                      /* the budget is a multiple of the unchecked block */
@@ -769,9 +781,15 @@ static int reserve_stream(fr_ctx* c, size_t npx, size_t nfields, bool f64, uint3
 
 /* reserve_only: do everything a render of this geometry would do BEFORE its first launch -- grow the survivor streams,
  * the Deep_Zoom orbit buffers, fill the exact-division cache -- and stop (fr_ctx_reserve). */
+static int enqueue_ssaa_staged(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* norm, uint32_t rows_local,
+                               float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only, bool out_frame);
+static int staging_threshold(const fr_params* p, size_t npx);
+
+/* ssaa_of > 1: this IS the sample grid of a supersampled res_w x res_h frame (enqueue_ssaa_staged): lean kernels only, the
+ * coordinate tables hold the samples' coordinates */
 static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* shard,
                           float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only = false,
-                          bool out_frame = false)
+                          bool out_frame = false, int ssaa_of = 0, uint32_t res_w = 0, uint32_t res_h = 0)
 {
     if (!reserve_only) {
         const int ov = check_overflow(c);          /* of an earlier asynchronous render nobody has asked about */
@@ -796,8 +814,31 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const bool effects = needs_effects(p);
     const int max_iter = p->max_iterations;
 
+    /* SSAA.  The sample loop of the general tile kernel runs a pixel's aa x aa samples one after the other, each to max_iter
+     * in lockstep with the 63 other pixels of its sub-tile: no compaction, no lane pool -- on escape-dense views a sample
+     * costs 1.6-1.8x what a pixel of the same view costs without SSAA (profiles/r04_ssaa_staged.txt).  Staged: the sample
+     * grid is a frame of W aa x H aa "pixels" whose coordinates are the samples' (prepare_kernel writes them into the lean
+     * kernels' tables), rendered through tile pass + lane pool into scratch planes, and ssaa_reduce_kernel averages.  Same
+     * arithmetic per sample, same summation order: bit-identical planes.  Applies where the lean kernels do (no effects,
+     * 8x8 sub-tiles, strips of whole sub-tile rows in sample space) and the sample grid is a legal frame (< 2^31 samples). */
+    if (ssaa_of <= 1 && p->antialiasing_samples > 1 && !effects && c->tune_ssaa != 1u) {
+        const uint32_t aa = (uint32_t)p->antialiasing_samples;
+        const uint64_t nsamples = (uint64_t)W * aa * (uint64_t)H * aa;
+        const bool lean_ok = c->tune_tile_kernel != 1u && (c->tune_shape == 0u || c->tune_shape == 3u) &&
+                             (norm.nparts == 1 || (norm.rows_per_strip * aa) % 8u == 0u);
+        /* (measured: -32 to -61 % on every view and size but the C2 frame with cycle closing off, +-2 %; also where the sample
+         * grid takes ONE pass -- 1080p at max_iter 256: -38 % -- because the lean kernel beats the general one.  The sample
+         * planes and the survivor stream of the sample grid are context scratch: 16 B + up to 60 B per sample; above 2^29
+         * samples -- 8192^2 at aa 3 -- the sample loop stays.) */
+        const bool fits = nsamples <= (1ull << 29) || c->tune_ssaa == 2u;
+        if (lean_ok && fits && nsamples < (1ull << 31) && (uint64_t)norm.rows_per_strip * aa <= 0xFFFFFFFFull)
+            return enqueue_ssaa_staged(c, p, W, H, &norm, rows_local, rgba, nu, iter, stream, reserve_only, out_frame);
+    }
+
     LaunchArgs a;
     fill_params(a, p);
+    a.ssaa = ssaa_of > 1 ? ssaa_of : 0;
+    a.res_w = (int32_t)res_w; a.res_h = (int32_t)res_h;
     a.W = (int32_t)W; a.H = (int32_t)H;
     a.rows_local = (int32_t)rows_local;
     a.part = (int32_t)norm.part; a.nparts = (int32_t)norm.nparts; a.rows_per_strip = (int32_t)norm.rows_per_strip;
@@ -880,6 +921,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      * whole sub-tile rows; "tile_kernel" = 1 keeps the general kernel (tests compare the two bitwise) */
     const bool lean = !effects && p->antialiasing_samples <= 1 && shape == 3 && c->tune_tile_kernel != 1u &&
                       (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
+    if (ssaa_of > 1 && !lean) return fr_set_error(FR_ERR_INTERNAL, "staged SSAA reached a render the lean tile kernel does not serve");
     if (lean) {
         const size_t need = ((size_t)W + H) * sizeof(double);
         if (need > c->coord_bytes) {
@@ -978,6 +1020,50 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     c->have_timing = true;
     c->last_stages = nstage;
     ++c->render_seq;
+    return FR_OK;
+}
+
+static int enqueue_ssaa_staged(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* norm, uint32_t rows_local,
+                               float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only, bool out_frame)
+{
+    const uint32_t aa = (uint32_t)p->antialiasing_samples;
+    const uint32_t Ws = W * aa, Hs = H * aa;
+    const size_t nsamp = (size_t)rows_local * aa * Ws;
+    const bool f64 = p->precision == FR_PRECISION_F64;
+    const size_t nu_elt = f64 ? 8 : 4;
+    /* sample planes: colour, then nu, then iter -- only those the caller's planes need */
+    const size_t off_nu = rgba ? nsamp * 16 : 0, off_iter = off_nu + (nu ? nsamp * nu_elt : 0), need = off_iter + (iter ? nsamp * 4 : 0);
+    if (need > c->ssaa_bytes) {
+        if (c->ssaa_buf) { (void)hipFree(c->ssaa_buf); c->ssaa_buf = nullptr; c->ssaa_bytes = 0; }
+        FR_HIP_TRY(hipMalloc(&c->ssaa_buf, need));
+        c->ssaa_bytes = need;
+    }
+    char* base = (char*)c->ssaa_buf;
+    float* s_rgba = rgba ? (float*)base : nullptr;
+    void* s_nu = nu ? (void*)(base + off_nu) : nullptr;
+    int32_t* s_iter = iter ? (int32_t*)(base + off_iter) : nullptr;
+    fr_params q = *p;
+    q.antialiasing_samples = 1;
+    q.flags &= ~FR_FLAG_POST_CHAIN;                            /* the post chain follows the average */
+    const fr_shard sh = {norm->part, norm->nparts, norm->rows_per_strip * aa};
+    int st = enqueue_render(c, &q, Ws, Hs, &sh, s_rgba, s_nu, s_iter, stream, reserve_only, false, (int)aa, W, H);
+    if (st != FR_OK || reserve_only) return st;
+    SsaaArgs r;
+    r.s_rgba = reinterpret_cast<const float4*>(s_rgba); r.s_nu = s_nu; r.s_iter = s_iter;
+    r.rgba = reinterpret_cast<float4*>(rgba); r.nu = nu; r.iter = iter;
+    r.W = (int32_t)W; r.rows_local = (int32_t)rows_local; r.aa = (int32_t)aa;
+    r.sx_outer = p->fractal_type == FR_FRACTAL_MANDELBROT ? 0 : 1;
+    r.part = (int32_t)norm->part; r.nparts = (int32_t)norm->nparts; r.rows_per_strip = (int32_t)norm->rows_per_strip; r.out_frame = out_frame ? 1 : 0;
+    r.flags = p->flags; r.brightness = p->color_brightness; r.saturation = p->color_saturation; r.contrast = p->color_contrast;
+    r.julia_floors = p->fractal_type != FR_FRACTAL_MANDELBROT ? 1 : 0;
+    size_t blocks = ((size_t)rows_local * W + kBlockThreads - 1) / kBlockThreads;
+    const size_t cap = (size_t)c->compute_units * 16;
+    if (blocks > cap) blocks = cap;
+    if (f64) hipLaunchKernelGGL(ssaa_reduce_kernel<double>, dim3((uint32_t)blocks), dim3(kBlockThreads), 0, stream, r);
+    else hipLaunchKernelGGL(ssaa_reduce_kernel<float>, dim3((uint32_t)blocks), dim3(kBlockThreads), 0, stream, r);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "SSAA reduce launch failed: %s", hipGetErrorString(e));
+    FR_HIP_TRY(hipEventRecord(c->ev_end, stream));             /* the frame's device time includes the average */
     return FR_OK;
 }
 

@@ -114,6 +114,9 @@ struct LaunchArgs {
     int32_t out_frame;           /* 1: the output planes are WHOLE-FRAME planes and the part's rows are stored in place
                                   * (frame row py), 0: the part's rows are stored packed (local row) -- FR_LAYOUT_FRAME */
     int32_t aa;
+    int32_t ssaa;                /* > 1: this render IS the sample grid of an aa x aa supersampled frame of res_w x res_h pixels
+                                  * (W = res_w * ssaa, H = res_h * ssaa): prepare_kernel writes the samples' coordinates */
+    int32_t res_w, res_h;
     /* colouring */
     int32_t palette_mode;
     float color_offset, color_scale;
@@ -1414,8 +1417,40 @@ prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n
     T* __restrict__ yds = reinterpret_cast<T*>(A.yds);
     if (!xs) return;
     const T center_x = (T)A.center_x, center_y = (T)A.center_y, zoom = (T)A.zoom;
-    const T resx = (T)A.W, resy = (T)A.H;
     const T aspect = sizeof(T) == 8 ? (T)A.aspect_d : (T)A.aspect_f;
+    if (A.ssaa > 1) {
+        /* the sample grid of a supersampled frame: column i = sample sx = i % aa of pixel column px = i / aa (rows alike),
+         * by the shaders' own sample expressions -- mandelbrot.comp:222-226 (offsets (sx, sy) / aa, top-left anchored),
+         * julia.comp:253-259 = burning_ship.comp:337-344 (centred offsets of 1 / (W aa), divided again by the size) -- as
+         * the SSAA arm of tile_kernel evaluates them per sample */
+        const int aa = A.ssaa;
+        const T resx = (T)A.res_w, resy = (T)A.res_h;
+        for (uint32_t i = first; i < (uint32_t)(A.W + A.H); i += stride) {
+            const bool col = i < (uint32_t)A.W;
+            const int g = col ? (int)i : (int)(i - (uint32_t)A.W);
+            const int pq = g / aa, sq = g - pq * aa;                 /* pixel and sample index along this axis */
+            if constexpr (MAP == 0) {
+                const T ps = (T)pq + (T)sq / (T)aa;
+                if (col) { const T uvx = (ps - T(0.5) * resx) / resy; xs[g] = center_x + uvx * zoom; }
+                else { const T uvy = (ps - T(0.5) * resy) / resy; yds[g] = T(2) * (center_y + uvy * zoom); }
+            } else {
+                const T pixel_size = T(1) / resx;
+                const T sample_offset = pixel_size / (T)aa;
+                const T centre = sample_offset * (T)(aa - 1) * T(0.5);
+                if (col) {
+                    T uvx = (T)pq / resx;
+                    uvx = uvx + ((T)sq * sample_offset - centre) / resx;
+                    xs[g] = center_x + (uvx - T(0.5)) * zoom * aspect;
+                } else {
+                    T uvy = (T)pq / resy;
+                    uvy = uvy + ((T)sq * sample_offset - centre) / resy;
+                    yds[g] = T(2) * (center_y + (uvy - T(0.5)) * zoom);
+                }
+            }
+        }
+        return;
+    }
+    const T resx = (T)A.W, resy = (T)A.H;
     for (uint32_t i = first; i < (uint32_t)(A.W + A.H); i += stride) {
         if (i < (uint32_t)A.W) {
             const int px = (int)i;
@@ -1436,6 +1471,53 @@ prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n
                 yds[py] = T(2) * (center_y + (uvy - T(0.5)) * zoom);
             }
         }
+    }
+}
+
+/* ---- staged SSAA: the average of a pixel's samples ------------------------------------------------------------------
+ * The sample grid (W aa x rows aa samples, packed local rows) was rendered like any frame -- lean tile pass + lane pool --
+ * into scratch planes; a pixel is the sum of its aa x aa sample colours in the shader's order (mandelbrot.comp:219-230: sy
+ * outer; julia.comp:253-262, burning_ship.comp:337-347: sx outer), divided by aa^2, then the post chain if asked for;
+ * nu and iter are those of sample (0, 0), as in the SSAA arm of tile_kernel.  HBM-bound: 16 aa^2 B read + 16 B written per
+ * pixel. */
+struct SsaaArgs {
+    const float4* s_rgba; const void* s_nu; const int32_t* s_iter;   /* sample planes (packed local sample rows) */
+    float4* rgba; void* nu; int32_t* iter;                           /* the frame's planes */
+    int32_t W, rows_local, aa, sx_outer;
+    int32_t part, nparts, rows_per_strip, out_frame;                 /* where local row r lives in a whole-frame plane */
+    uint32_t flags; float brightness, saturation, contrast; int32_t julia_floors;
+};
+template <typename T>
+__global__ void __launch_bounds__(kBlockThreads)
+ssaa_reduce_kernel(const SsaaArgs A)
+{
+    const size_t npx = (size_t)A.W * (size_t)A.rows_local;
+    const int aa = A.aa;
+    const size_t Ws = (size_t)A.W * (size_t)aa;
+    for (size_t i = (size_t)blockIdx.x * kBlockThreads + threadIdx.x; i < npx; i += (size_t)gridDim.x * kBlockThreads) {
+        const uint32_t lrow = (uint32_t)(i / (size_t)A.W), px = (uint32_t)(i - (size_t)lrow * A.W);
+        uint32_t row = lrow;
+        if (A.out_frame && A.nparts != 1) {
+            const uint32_t strip = lrow / (uint32_t)A.rows_per_strip;
+            row = (strip * (uint32_t)A.nparts + (uint32_t)A.part) * (uint32_t)A.rows_per_strip + (lrow - strip * (uint32_t)A.rows_per_strip);
+        }
+        const size_t o = (size_t)row * A.W + px;
+        const size_t s00 = (size_t)lrow * aa * Ws + (size_t)px * aa;
+        if (A.rgba) {
+            float acc[3] = {0.0f, 0.0f, 0.0f};
+            for (int s = 0; s < aa * aa; ++s) {
+                const int a = s / aa, b = s - a * aa;                /* outer, inner */
+                const int sy = A.sx_outer ? b : a, sx = A.sx_outer ? a : b;
+                const float4 v = A.s_rgba[s00 + (size_t)sy * Ws + sx];
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z;
+            }
+            const float n = (float)(aa * aa);
+            acc[0] /= n; acc[1] /= n; acc[2] /= n;
+            if (A.flags & FR_FLAG_POST_CHAIN) post_chain(acc, A.brightness, A.saturation, A.contrast, A.julia_floors != 0);
+            A.rgba[o] = make_float4(acc[0], acc[1], acc[2], 1.0f);
+        }
+        if (A.nu) reinterpret_cast<T*>(A.nu)[o] = reinterpret_cast<const T*>(A.s_nu)[s00];
+        if (A.iter) A.iter[o] = A.s_iter[s00];
     }
 }
 

@@ -24,6 +24,8 @@
  *                        0 = automatic (= 2)
  *   "tile_pixels"        1 / 2 sub-tiles per trip of the lean tile kernel (0 = 2)
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1 (general tile kernel)
+ *   "ssaa"               SSAA: 0 = automatic (staged wherever the lean kernels apply and the sample grid has <= 2^29 samples),
+ *                        1 = the sample loop of the general tile kernel, 2 = staged wherever it applies
  *   "debug_region_blocks" caps the capacity of a survivor-stream region so that the overflow report (FR_ERR_INTERNAL)
  *                        can be exercised; 0 = the real capacity (1.5x the worst case)
  */

@@ -1410,6 +1410,64 @@ def test_rccl_plugin_next_to_torch(fr):
     assert any("librccl" in m for m in maps), maps
 
 
+def test_staged_ssaa_is_bit_identical_to_the_sample_loop(fr, renderer):
+    """SSAA two ways: the sample loop of the general tile kernel ("ssaa" = 1: a pixel's aa x aa samples one after the other in
+    lockstep) and the staged form ("ssaa" = 2: the sample grid rendered as a frame of its own through the lean tile pass and the
+    lane pool -- its coordinate tables hold the shaders' sample positions --, then averaged in the shader's order).  Every
+    plane must be bit-identical: Mandelbrot / Julia / Burning Ship (sy-outer and sx-outer sample orders), fp64 / fp32, aa 2
+    and 3, post chain, ragged sizes, row strips (packed and whole-frame planes) and the automatic choice."""
+    import torch
+    cases = [(fr.FractalType.Mandelbrot, fr.Precision.F64, dict(max_iterations=1024)),
+             (fr.FractalType.Mandelbrot, fr.Precision.F32, dict(max_iterations=900, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.02)),
+             (fr.FractalType.JuliaSet, fr.Precision.F32, dict(max_iterations=800, center_x=0.0, julia_c_real=-0.8, julia_c_imag=0.156)),
+             (fr.FractalType.JuliaSet, fr.Precision.F64, dict(max_iterations=300, center_x=0.0, julia_c_real=-0.123, julia_c_imag=0.745)),
+             (fr.FractalType.BurningShip, fr.Precision.F64, dict(max_iterations=600, center_x=-1.755, center_y=-0.03, zoom=0.1))]
+    W, H = 203, 118
+    try:
+        for ft, prec, kw in cases:
+            nu_dt = torch.float64 if prec == fr.Precision.F64 else torch.float32
+            for aa, post in ((2, False), (3, True)):
+                st = fr.FractalState(antialiasing_samples=aa, **kw)
+
+                def run(mode, shard=None, rows=H):
+                    renderer.set_option("ssaa", mode)
+                    out = (torch.full((rows, W, 4), -1.0, dtype=torch.float32, device="cuda"), torch.full((rows, W), -1.0, dtype=nu_dt, device="cuda"),
+                           torch.full((rows, W), -1, dtype=torch.int32, device="cuda"))
+                    torch.cuda.synchronize()
+                    renderer.render(st, W, H, fractal_type=ft, precision=prec, post_chain=post, rgba=out[0], nu=out[1], iter=out[2], shard=shard)
+                    return out
+
+                want = run(1)
+                assert renderer.last_stages() == 1                              # the sample loop is one pass
+                got = run(2)
+                for a, b in zip(want, got):
+                    assert torch.equal(a, b), (ft, prec, aa)
+                auto = run(0)
+                for a, b in zip(want, auto):
+                    assert torch.equal(a, b), (ft, prec, aa, "auto")
+                for part in range(3):                                           # strips of 8 rows: whole sub-tile rows in sample space
+                    sh = fr.Shard(part, 3, 8)
+                    rows = sh.rows(H)
+                    w2, g2 = run(1, sh, rows), run(2, sh, rows)
+                    for a, b in zip(w2, g2):
+                        assert torch.equal(a, b), (ft, prec, aa, part)
+                    idx = torch.from_numpy(sh.global_rows(H)).to("cuda")
+                    assert torch.equal(g2[0], want[0][idx]) and torch.equal(g2[2], want[2][idx])
+        # through fr_node: whole-frame planes (FR_LAYOUT_FRAME), two parts
+        st = fr.FractalState(antialiasing_samples=2, max_iterations=1024)
+        renderer.set_option("ssaa", 1)
+        want = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+        renderer.render(st, W, H, rgba=want)
+        with fr.Node([0, 0]) as node:
+            node.set_tuning("ssaa", 2)
+            got = torch.zeros_like(want)
+            torch.cuda.synchronize()
+            node.render(st, W, H, rgba=got)
+            assert torch.equal(got, want)
+    finally:
+        renderer.set_option("ssaa", 0)
+
+
 def test_bench_node_host_and_default_lines(fr):
     """bench.py keeps its contract on the C-ABI host: `--host node` (ONE process, fr_node: every gather x mode pair the box
     allows, here with two parts on this card and the one-rank RCCL loopback with one) prints ONE JSON line with the
