@@ -1206,6 +1206,12 @@ def test_node_render_animation_matches_single_gpu_pngs(fr, renderer, tmp_path, n
         ref_path = str(tmp_path / "ref_win.png")
         assert renderer.render_frame(st, 96, 64, ref_path, precision=fr.Precision.F64)
         assert open(ref_path, "rb").read() == open(os.path.join(out2, "frame_001002.png"), "rb").read()
+        # the perturbation shader's frames (no post chain in the shader: fr_render_frame_png's rule), two frames
+        out3 = str(tmp_path / "dz")
+        assert node.render_animation(anim, out3, width=80, height=64, first_frame=2390, frame_count=2, fractal_type=fr.FractalType.Deep_Zoom) == 2
+        ref_path = str(tmp_path / "ref_dz.png")
+        assert renderer.render_frame(anim.interpolate(anim.frame_time(2391)), 80, 64, ref_path, fractal_type=fr.FractalType.Deep_Zoom)
+        assert open(ref_path, "rb").read() == open(os.path.join(out3, "frame_002391.png"), "rb").read()
         one = fr.AnimationSystem()
         one.add_keyframe(0.0, fr.FractalState())
         with pytest.raises(fr.FractalRendererError) as e:
