@@ -171,7 +171,7 @@ INTERNAL_SIGNATURES = {
     "fr_node_rccl_usable": (C.c_int, [C.c_void_p]),
     "fr_node_mapped_runtimes": (C.c_int, [C.c_char_p, C.c_size_t]),
 }
-PUBLIC_OPTIONS = ("periodicity", "staging", "shards", "tile_kernel", "diag_buffer", "diag_stride")
+PUBLIC_OPTIONS = ("periodicity", "staging", "shards", "tile_kernel", "timing", "diag_buffer", "diag_stride")
 TUNING_NAMES = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "stage_first", "pool_refill_at", "stream_run_max",
                 "stream_run_min", "stream_workgroups_per_cu", "probes", "stream_probes", "regions", "stream_rotate",
                 "tile_pixels", "pool_items_per_wg", "subtile_shape", "debug_region_blocks", "ssaa")

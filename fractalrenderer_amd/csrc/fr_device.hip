@@ -31,7 +31,13 @@ struct fr_ctx {
     int compute_units;
     hipStream_t stream;
     hipEvent_t ev_begin, ev_end;
-    bool have_timing;
+    bool have_timing;           /* ev_begin / ev_end hold the most recent render (only recorded with "timing" on) */
+    bool timing;                /* option "timing": record the event pair around every render (fr_ctx_last_kernel_ms).  Off by
+                                 * default since 1.1: two timed event records cost a frame ~4.7 us (C2 0.6 %, C3 1.8 %, a 1080p
+                                 * frame at max_iter 256 10 %: profiles/r04_timing_events.txt) */
+    bool have_render;           /* a render has been enqueued: last_stream is where */
+    hipStream_t last_stream;    /* the stream of the most recent render */
+    hipEvent_t ev_order;        /* no timing: recorded on last_stream when somebody has to wait for that render */
     uint32_t* d_ctrl;           /* queue heads + stream counters of every stage (kCtrlWords) */
     void* frame_buf;            /* fr_render_frame_png: RGBA f32 frame + RGB8 */
     size_t frame_bytes;
@@ -134,6 +140,7 @@ extern "C" int fr_ctx_create(int device_ordinal, fr_ctx** out)
     if ((e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_begin)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_end)) != hipSuccess ||
+        (e2 = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming)) != hipSuccess ||
         (e2 = hipMalloc((void**)&c->d_ctrl, (kCtrlWords + (size_t)(kFeedbackShards + 1) * kShardStrideWords) * sizeof(uint32_t))) != hipSuccess ||
         (e2 = hipMemset(c->d_ctrl, 0, (kCtrlWords + (size_t)(kFeedbackShards + 1) * kShardStrideWords) * sizeof(uint32_t))) != hipSuccess ||
         (e2 = hipHostMalloc((void**)&c->overflow_host, 64, hipHostMallocMapped)) != hipSuccess ||
@@ -170,6 +177,7 @@ extern "C" void fr_ctx_destroy(fr_ctx* c)
     if (c->orbit_dev) (void)hipFree(c->orbit_dev);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     free(c);
 }
@@ -198,6 +206,10 @@ extern "C" int fr_ctx_set_option(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "tile_kernel")) {
         if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "tile_kernel must be 0 (automatic: lean where it applies) or 1 (general)");
         c->tune_tile_kernel = (uint32_t)value;
+    } else if (!strcmp(name, "timing")) {
+        if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "timing must be 0 (off) or 1 (an event pair around every render: fr_ctx_last_kernel_ms)");
+        c->timing = value != 0;
+        if (!c->timing) c->have_timing = false;
     } else if (!strcmp(name, "diag_buffer")) {
         c->diag = (uint64_t*)(uintptr_t)value;        /* device pointer, 4 x u64 per wave of the grid; 0 = off */
     } else if (!strcmp(name, "diag_stride")) {
@@ -514,8 +526,12 @@ static hipError_t clear_control_block(fr_ctx* c, hipStream_t stream, int nstages
  * was enqueued on a CALLER's stream: ev_end was recorded there behind the last launch. */
 static hipError_t order_after_last_render(fr_ctx* c, hipStream_t s)
 {
-    if (!c->render_on_user_stream || !c->have_timing) return hipSuccess;
-    return hipStreamWaitEvent(s, c->ev_end, 0);
+    if (!c->render_on_user_stream || !c->have_render || c->last_stream == s) return hipSuccess;
+    /* recorded NOW, on the stream that render went to: behind it (and behind whatever the caller has enqueued there since) --
+     * the renders themselves record nothing for this */
+    const hipError_t e = hipEventRecord(c->ev_order, c->last_stream);
+    if (e != hipSuccess) return e;
+    return hipStreamWaitEvent(s, c->ev_order, 0);
 }
 
 /* Deep_Zoom: what VulkanEngine::prepare_deep_zoom_rendering + dispatch do per frame
@@ -584,12 +600,14 @@ static int enqueue_deep_zoom(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t
     c->last_stages = 1;
 
     FR_HIP_TRY(clear_control_block(c, stream, 1));
-    FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
+    if (c->timing) FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
     hipLaunchKernelGGL((deep_zoom_kernel<3>), dim3(grid), dim3(kBlockThreads), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "deep-zoom kernel launch failed: %s", hipGetErrorString(e));
-    FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
-    c->have_timing = true;
+    if (c->timing) FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
+    c->have_timing = c->timing;
+    c->have_render = true;
+    c->last_stream = stream;
     ++c->render_seq;                             /* its first launch forwarded the previous render's verdict (Feedback) */
     c->last_pool_closing = -1;
     return FR_OK;
@@ -936,7 +954,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     if (reserve_only) return FR_OK;
 
     /* the frame's device time (fr_ctx_last_kernel_ms) includes the small launch that prepares it */
-    FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
+    if (c->timing) FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
     if (lean) {
         hipError_t ep = by_variant(fractal, f64, [&](auto t, auto f) {
             return launch_prepare<decltype(t), decltype(f)::value>(stream, a, c->d_ctrl, (uint32_t)((size_t)nstage * kStageWords), feedback_of(c)); });
@@ -1016,8 +1034,10 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
             return launch_stream_pool<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
         if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "lane-pool kernel launch failed: %s", hipGetErrorString(e));
     }
-    FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
-    c->have_timing = true;
+    if (c->timing) FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
+    c->have_timing = c->timing;
+    c->have_render = true;
+    c->last_stream = stream;
     c->last_stages = nstage;
     ++c->render_seq;
     return FR_OK;
@@ -1063,7 +1083,7 @@ static int enqueue_ssaa_staged(fr_ctx* c, const fr_params* p, uint32_t W, uint32
     else hipLaunchKernelGGL(ssaa_reduce_kernel<float>, dim3((uint32_t)blocks), dim3(kBlockThreads), 0, stream, r);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "SSAA reduce launch failed: %s", hipGetErrorString(e));
-    FR_HIP_TRY(hipEventRecord(c->ev_end, stream));             /* the frame's device time includes the average */
+    if (c->timing) FR_HIP_TRY(hipEventRecord(c->ev_end, stream));      /* the frame's device time includes the average */
     return FR_OK;
 }
 
@@ -1118,7 +1138,7 @@ extern "C" int fr_ctx_reserve(fr_ctx* c, const fr_params* p, uint32_t W, uint32_
     /* growing a buffer frees the old one, which a render still in flight may be reading: wait for the context's own
      * stream and, when the most recent render went to a caller's stream, for the event recorded behind it there */
     FR_HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->render_on_user_stream && c->have_timing) FR_HIP_TRY(hipEventSynchronize(c->ev_end));
+    if (c->render_on_user_stream && c->have_render) FR_HIP_TRY(hipStreamSynchronize(c->last_stream));
     return enqueue_render(c, p, W, H, shard, nullptr, nullptr, nullptr, c->stream, true);
 }
 

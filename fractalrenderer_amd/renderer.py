@@ -51,12 +51,17 @@ def _is_torch(x) -> bool:
 class Renderer:
     """One fr_ctx bound to one HIP device."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, timing: bool = True):
+        """timing: option "timing" -- the event pair around every render that last_kernel_ms() reads.  The C library's
+        default is OFF (two timed event records cost a frame ~4.7 us); this wrapper, which tests and tools measure with,
+        switches it on unless told otherwise (bench.py's timed contexts are told otherwise)."""
         self._lib = _capi.lib()
         h = C.c_void_p()
         _capi.check(self._lib.fr_ctx_create(int(device), C.byref(h)))
         self._ctx = h
         self.device = int(device)
+        if timing:
+            self.set_option("timing", 1)
 
     def close(self) -> None:
         if getattr(self, "_ctx", None):

@@ -225,9 +225,10 @@ int fr_ctx_reserve(fr_ctx* ctx, const fr_params* p, uint32_t width, uint32_t hei
  * _async forms calls this after it has synchronised its stream. */
 int fr_ctx_check(fr_ctx* ctx);
 
-/* Device time of the most recent render's kernel on this context, from a HIP event pair
- * recorded around the launch on the launch stream (blocks until that kernel is done).
- * < 0 if nothing was rendered yet. */
+/* Device time of the most recent render's kernels on this context, from a HIP event pair recorded around its launches on
+ * the launch stream (blocks until they are done).  Needs the option "timing" = 1, set BEFORE that render: the pair is not
+ * recorded by default since 1.1 (two timed event records cost a frame ~4.7 us -- 0.6 % of a 4096^2 / 1024 frame, 10 % of a
+ * 1080p / 256 one).  < 0 if nothing was rendered with it yet. */
 float fr_ctx_last_kernel_ms(fr_ctx* ctx);
 
 /* Options by name; value 0 restores the automatic choice (made per launch from the frame geometry).  None of them can
@@ -255,6 +256,8 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "tile_kernel"   1 = the general tile kernel; 0 = automatic: the LEAN tile kernel (coordinate tables written by a small
  *                   launch in front of the render, two 8x8 sub-tiles per wave and trip) for every one-sample render
  *                   without effects whose row strips, if sharded, are whole sub-tile rows.
+ *   "timing"        1 = record a HIP event pair around every render (fr_ctx_last_kernel_ms, fr_node_last_kernel_ms); 0 = off, the
+ *                   default since 1.1.
  *   "diag_buffer"   device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks, items processed, dequeues);
  *                   0 disables.  "diag_stride" = uint64 words between the tile pass's and the lane pool's regions.
  * Changed in 1.0 (INTEGRATION.md lists the breaks): "periodicity" 0 means automatic = ON since 0.2 (it meant off in
@@ -342,7 +345,8 @@ int  fr_node_wait(fr_node* node);
 int  fr_node_in_flight(const fr_node* node);
 /* the gather the most recently submitted frame uses (fr_gather, never AUTO), or < 0 before the first one */
 int  fr_node_last_gather(const fr_node* node);
-/* device time of part `part`'s kernels of the most recently submitted frame (fr_ctx_last_kernel_ms of its context) */
+/* device time of part `part`'s kernels of the most recently submitted frame (fr_ctx_last_kernel_ms of its context: needs the
+ * option "timing" = 1 on the node) */
 float fr_node_last_kernel_ms(fr_node* node, int part);
 
 /* AnimationRenderer::start_render (src/animation_renderer.cpp:26-152) over the GPUs of a node: for frame = first, first +

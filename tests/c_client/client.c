@@ -89,7 +89,9 @@ static int gpu_part(const char* png)
     /* conjugate symmetry: rows y and H - y */
     for (int y = 1; y < H / 2; ++y)
         for (int x = 0; x < W; ++x) CHECK(it[y * W + x] == it[(H - y) * W + x]);
-    CHECK(fr_ctx_last_kernel_ms(ctx) > 0.0f);
+    CHECK(fr_ctx_last_kernel_ms(ctx) < 0.0f);                      /* no event pair around a render unless asked for (1.1) */
+    CHECK(fr_ctx_set_option(ctx, "timing", 1) == FR_OK);
+    CHECK(fr_render(ctx, &p, W, H, &out) == FR_OK && fr_ctx_last_kernel_ms(ctx) > 0.0f);
 
     /* a part of a sharded frame equals the rows of the whole frame */
     fr_shard sh = {1u, 2u, 8u};

@@ -108,6 +108,8 @@ static int lanes_part(void)
         CHECK(fr_node_render(node, &p, 64, 64, n, &so) == FR_ERR_INVALID_ARG);
         /* async + wait; an option of the contexts reaches every part */
         CHECK(fr_node_set_option(node, "periodicity", -1) == FR_OK);
+        CHECK(fr_node_last_kernel_ms(node, n - 1) < 0.0f);                                /* no event pair unless asked for (1.1) */
+        CHECK(fr_node_set_option(node, "timing", 1) == FR_OK);
         CHECK(fr_node_render_async(node, &p, 64, 64, 0, &so) == FR_OK);
         CHECK(fr_node_render_async(node, &p, 64, 64, 0, &so) == FR_OK);                  /* a second frame in flight (1.1) */
         CHECK(fr_node_in_flight(node) == 2);
