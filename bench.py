@@ -35,6 +35,12 @@ Under the driver's torch.distributed.run command (WORLD_SIZE set, N > 1) the tor
 an informational "fr_node" object, measured in-process after the timed region while the other ranks wait at a host-side
 (gloo) barrier; FR_BENCH_NODE_LEG=0 switches that leg off.
 
+Order of the N = 1 legs: the informational `periodicity` leg (the library's default, cycle closing on) runs first, the
+headline leg behind it -- each is W untimed + K timed steps of the full frame; a GPU that has been idle takes tens of
+milliseconds of load to reach its sustained clocks (tools/clock_ramp.py), and a 20-step headline leg right behind the
+process's first kernel would time that ramp.  The line says so (`leg_order`).  The render contexts run with the library's
+default `timing` = off (no HIP event pair around every render): the timed region is measured with events of its own.
+
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline       the metric's own roofline ("achieved HBM GB/s vs peak"): algorithmic bytes
                  16 B/pixel (RGBA f32, write-once) / average kernel time measured with HIP events
