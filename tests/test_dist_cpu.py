@@ -193,3 +193,15 @@ def test_bench_launcher_does_not_touch_torch_or_the_gpu_before_spawning():
     main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
     seg = ast.get_source_segment(src, main)
     assert seg.index("HSA_ENABLE_IPC_MODE_LEGACY") < seg.index("launch_ranks(") < seg.index("import torch")
+
+
+def test_bench_node_host_refuses_what_it_cannot_do(fr):
+    """`bench.py --host node` is ONE process driving all devices through the C ABI: under torch.distributed.run (WORLD_SIZE set)
+    it refuses instead of starting one node per rank, and without a GPU it says so (no CPU path); both before any rank is
+    spawned."""
+    out = _bench("--gpus", "2", "--host", "node", env_extra={"WORLD_SIZE": "2", "RANK": "0"})
+    assert out.returncode != 0 and "ONE process" in (out.stderr + out.stdout)
+    import torch
+    if not torch.cuda.is_available():
+        out = _bench("--gpus", "1", "--host", "node")
+        assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
