@@ -165,6 +165,13 @@ int fr_write_png(const char* path, uint32_t width, uint32_t height, int32_t bit_
     memset(&job, 0, sizeof(job));
     job.rgb = rgb; job.width = width; job.bit_depth = bit_depth; job.row = row;
     job.level = bit_depth == 16 ? 9 : 6;                          /* png_set_compression_level(9), :2132 */
+    if (bit_depth == 8) {
+        /* 8-bit animation frames: the pixels are what must equal the reference's stbi_write_png output, not the deflate
+         * stream.  FR_PNG_LEVEL = 1..9 picks the zlib level (default 6): an animation export is bound by this deflate
+         * (profiles/r04_anim_sweep.txt) */
+        const char* e = getenv("FR_PNG_LEVEL");
+        if (e && atoi(e) >= 1 && atoi(e) <= 9) job.level = atoi(e);
+    }
     job.nbands = nbands;
     job.bands = (png_band*)calloc(nbands, sizeof(png_band));
     if (!job.bands) return fr_set_error(FR_ERR_NOMEM, "out of memory");

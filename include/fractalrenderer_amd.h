@@ -423,7 +423,8 @@ typedef struct fr_png_text { const char* key; const char* text; } fr_png_text;  
  * stbi_write_png produces pixel-wise (src/vk_engine.cpp:1374-1381); bit_depth 16: host-endian uint16
  * samples written big-endian, compression level 9 (src/vk_engine.cpp:2114-2208).  print_metadata != 0
  * adds what the print export adds: gAMA 1/2.2, sRGB perceptual, pHYs 300 dpi, tIME; `texts` become
- * uncompressed tEXt chunks. */
+ * uncompressed tEXt chunks.  The deflate is band-parallel (FR_PNG_THREADS, default: all cores); for 8-bit files the
+ * environment variable FR_PNG_LEVEL = 1..9 picks the zlib level (default 6: an animation export is bound by it). */
 int fr_write_png(const char* path, uint32_t width, uint32_t height, int32_t bit_depth, const void* rgb,
                  const fr_png_text* texts, int32_t ntexts, int32_t print_metadata);
 

@@ -29,8 +29,9 @@ try:
             n = node.render_animation(anim, out, width=size, height=size, frame_step=100, precision=fr.Precision.F64, max_iterations=4096)
             dt = time.perf_counter() - t0
         same = open(os.path.join(out, "frame_000500.png"), "rb").read() == open(os.path.join(tmp, "one_000500.png"), "rb").read()
+        mb = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / n / 1e6
         print(f"  fr_node_render_animation, {parts} part(s) on device 0, {slots} slot(s): {n} frames in {dt:.2f} s = {dt / n * 1e3:.1f} ms/frame "
-              f"({size * size * n / dt / 1e6:.0f} Mpx/s end to end, PNG files included); frame 500 identical: {same}")
+              f"({size * size * n / dt / 1e6:.0f} Mpx/s end to end, PNG files included, {mb:.1f} MB per file, FR_PNG_LEVEL={os.environ.get('FR_PNG_LEVEL', '6 (default)')}); frame 500 identical: {same}")
         shutil.rmtree(out)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
