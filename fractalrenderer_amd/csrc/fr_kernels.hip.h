@@ -205,8 +205,11 @@ template <> struct Real<double> {
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
     static __device__ __forceinline__ double fmin(double a, double b) { return ::fmin(a, b); }
-    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
-    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    /* NOT inlined: the fp64 atan2 and sin of the stripe epilogue (once per pixel) held the whole effects variant of the tile
+     * kernel at 156 VGPRs = 3 waves per SIMD; called, it takes 95 = 5, what the launcher's 5 workgroups per CU assume
+     * (trap -2 %, stripes -4 %; same library routines on the same values: bit-identical) */
+    static __device__ __attribute__((noinline)) double atan2(double y, double x) { return ::atan2(y, x); }
+    static __device__ __attribute__((noinline)) double sin(double x) { return ::sin(x); }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static constexpr double ln2() { return 0.693147180559945309417232121458; }
 };

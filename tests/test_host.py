@@ -592,8 +592,9 @@ def test_hot_kernels_keep_their_register_budget(fr):
         "_ZN2fr11tile_kernelIdLi0ELi3ELb0ELb0ELb1EEEvNS_10LaunchArgsE": (96, 5, 48),
         "_ZN2fr11tile_kernelIdLi0ELi3ELb0ELb0ELb0EEEvNS_10LaunchArgsE": (96, 5, 48),
         "_ZN2fr11tile_kernelIfLi1ELi3ELb0ELb0ELb0EEEvNS_10LaunchArgsE": (64, 5, 24),
-        # the effects variant (orbit trap / stripes): its fp64 atan2 + sin epilogue holds it at 3 waves per SIMD
-        "_ZN2fr11tile_kernelIdLi0ELi3ELb1ELb0ELb0EEEvNS_10LaunchArgsE": (168, 3, 32),
+        # the effects variant (orbit trap / stripes): its fp64 atan2 + sin epilogue is CALLED since round 4 (inlined it held the
+        # kernel at 156 VGPRs = 3 waves per SIMD)
+        "_ZN2fr11tile_kernelIdLi0ELi3ELb1ELb0ELb0EEEvNS_10LaunchArgsE": (112, 5, 24),
     }
     for name, (max_vgpr, min_occ, max_spill) in budget.items():
         u = usage.get(name)
