@@ -78,6 +78,9 @@ struct fr_ctx {
     uint32_t tune_shards;       /* 0 = automatic, 8 or 64: queue shards / stream regions of a render */
     uint32_t tune_regions;      /* 0 = automatic (= shards), 8 or 64: regions of the survivor streams */
     uint32_t tune_tile_pixels;  /* lean tile kernel: sub-tiles (pixels per lane) per trip, 0 = automatic (2), 1 or 2 */
+    uint32_t tune_tile_exit;    /* lean tile pass, staged: occupancy exit -- 0 = automatic, 1 = off, else the per-record cost of the
+                                   lane pool in updates that the exit rule assumes (escape_run_lean) */
+    uint32_t tune_tile_exit_from; /* ... and the updates a trip runs before it may leave (0 = automatic) */
     uint32_t tune_pool_items_per_wg; /* lane pool grid: at most one workgroup per this many sub-tiles of the frame (0 = 32) */
     uint32_t* overflow_host;    /* pinned, device-mapped word: a survivor stream ran out of blocks (see StreamRef::overflow) */
     uint32_t* overflow_dev;     /* the same word as the kernels address it */
@@ -272,6 +275,12 @@ extern "C" int fr_ctx_set_tuning(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "tile_pixels")) {
         if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "tile_pixels must be 0 (automatic), 1 or 2");
         c->tune_tile_pixels = (uint32_t)value;
+    } else if (!strcmp(name, "tile_exit")) {
+        if (value < 0 || value > 4096) return fr_set_error(FR_ERR_INVALID_ARG, "tile_exit must be 0 (automatic), 1 (off) or a cost in updates up to 4096");
+        c->tune_tile_exit = (uint32_t)value;
+    } else if (!strcmp(name, "tile_exit_from")) {
+        if (value < 0 || value > (1 << 24)) return fr_set_error(FR_ERR_INVALID_ARG, "tile_exit_from out of range");
+        c->tune_tile_exit_from = (uint32_t)value;
     } else if (!strcmp(name, "ssaa")) {
         if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "ssaa must be 0 (automatic), 1 (sample loop of the general tile kernel) or 2 (staged)");
         c->tune_ssaa = (uint32_t)value;
@@ -803,6 +812,11 @@ static int enqueue_ssaa_staged(fr_ctx* c, const fr_params* p, uint32_t W, uint32
                                float* rgba, void* nu, int32_t* iter, hipStream_t stream, bool reserve_only, bool out_frame);
 static int staging_threshold(const fr_params* p, size_t npx);
 
+/* occupancy exit of the lean tile pass (escape_run_lean): what a record costs the lane pool, in updates, and the updates a
+ * trip runs before it may leave */
+constexpr uint32_t kTileExitCost = 48u;
+constexpr uint32_t kTileExitFrom = 32u;
+
 /* ssaa_of > 1: this IS the sample grid of a supersampled res_w x res_h frame (enqueue_ssaa_staged): lean kernels only, the
  * coordinate tables hold the samples' coordinates */
 static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H, const fr_shard* shard,
@@ -968,6 +982,15 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     a.q.heads = stage_heads(c, 0);
     a.i0 = 0;
     a.i1 = bounds[0];
+    a.exit_from = 0;
+    a.exit_cost = 0u;
+    if (staged && lean && c->tune_tile_exit != 1u) {
+        a.exit_cost = c->tune_tile_exit ? c->tune_tile_exit : kTileExitCost;
+        /* not in the first half of the budget (C5, b0 192: 4.22 -> 4.09 ms leaving from 64, 4.06 from 96; C2, b0 96: +-0.3 %
+         * whatever the rule -- profiles/r04_tile_occupancy_exit.txt) */
+        const uint32_t half = ((uint32_t)bounds[0] / 2u + 15u) / 16u * 16u;
+        a.exit_from = (int32_t)(c->tune_tile_exit_from ? c->tune_tile_exit_from : (half > kTileExitFrom ? half : kTileExitFrom));
+    }
     if (staged) {
         a.out.base = (uint8_t*)c->stream_buf;
         a.out.n_blocks = stage_counter(c, 0);

@@ -141,6 +141,9 @@ struct LaunchArgs {
     int32_t lib_log;             /* bailout <= 1: smooth count through the library log(), as written */
     /* stage: this launch runs iterations [i0, i1); i1 < max_iter -> unfinished pixels go to `out` */
     int32_t i0, i1;
+    /* lean tile pass, staged: a trip whose live samples are few leaves before i1 (escape_run_lean); 0 = never */
+    int32_t exit_from;
+    uint32_t exit_cost;
     StreamRef in, out;
     uint32_t pool_refill_at;     /* lane pool: finished lanes wait until this many are idle */
     uint32_t period_window;      /* lane pool, PERIOD variant: iterations between the snapshots cycles are looked for against */
@@ -1545,9 +1548,10 @@ ssaa_reduce_kernel(const SsaaArgs A)
  * (every few instructions one waits for the other: v_cmp -> branch, exec write -> VALU; measured: VALU and SALU + branch
  * cycles add up to ~85 % of the pass), so halving the scalar work per pixel is worth as much as removing vector work. */
 template <typename T, int NP, bool ABS, bool PERIOD>
-__device__ __forceinline__ void escape_run_lean(Orbit<T> (&o)[NP], const T B2x4, const int i1, const bool fast_ok, bool fast,
-                                                const bool (&lane_off)[NP], int (&esc_i)[NP], T (&esc_r2x4)[NP],
-                                                uint64_t (&done)[NP], const uint32_t period_window)
+__device__ __forceinline__ int escape_run_lean(Orbit<T> (&o)[NP], const T B2x4, const int i1, const bool fast_ok, bool fast,
+                                               const bool (&lane_off)[NP], int (&esc_i)[NP], T (&esc_r2x4)[NP],
+                                               uint64_t (&done)[NP], const uint32_t period_window,
+                                               const int exit_from, const uint32_t exit_cost)
 {
     using Bits = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
     constexpr Bits kNaNBits = sizeof(T) == 8 ? (Bits)0x7FF8000000000000ull : (Bits)0x7FC00000u;
@@ -1595,6 +1599,19 @@ __device__ __forceinline__ void escape_run_lean(Orbit<T> (&o)[NP], const T B2x4,
     while (i < i1) {
         if (all == ~0ull) break;                           /* every lane finished: wave-uniform early-out */
         const int left = i1 - i;
+        /* OCCUPANCY EXIT (staged passes).  The trip pays NP x 64 slots per update whatever the number of live samples; the
+         * lane pool pays per live sample, plus `exit_cost` updates' worth of handling per record (stream write and read,
+         * refill, half a stretch idle, a replay of its escape).  Once the live samples are few enough that handing them
+         * over now is the cheaper side of that -- alive x (left + exit_cost) < slots x left -- the trip ends here and its
+         * survivors go to the stream with the updates they have run (the pool honours every record's own count).  Same
+         * operations per sample in the same order: only WHERE a sample's later updates run changes, never a pixel. */
+        if (exit_cost != 0u && i >= exit_from) {
+            uint32_t fin = 0;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) fin += (uint32_t)__builtin_popcountll(done[p]);
+            const uint32_t alive = (uint32_t)(NP * 64) - fin;
+            if (alive * ((uint32_t)left + exit_cost) < (uint32_t)(NP * 64) * (uint32_t)left) break;
+        }
         if (fast && left >= kFastBlock) {
             Orbit<T> snap[NP];
 #pragma unroll
@@ -1647,6 +1664,7 @@ __device__ __forceinline__ void escape_run_lean(Orbit<T> (&o)[NP], const T B2x4,
         fast = fast_ok && !event;
         if constexpr (PERIOD) { if (period_window) close_cycles(); }
     }
+    return i;                                              /* updates the trip's unfinished samples have run */
 }
 
 /* WaveQueue with only its three words of state kept between calls (home shard, shards tried, head last seen) */
@@ -1837,8 +1855,8 @@ tile_lean_kernel(const LaunchArgs A)
                 int it[NP];
                 T r2x4[NP];
                 uint64_t done[NP];
-                escape_run_lean<T, NP, ABS, PERIOD>(o, B2x4, i1, fast_ok, hint_fast && fast_ok, lane_off, it, r2x4, done,
-                                                    PERIOD ? A.period_window : 0u);
+                const int i_end = escape_run_lean<T, NP, ABS, PERIOD>(o, B2x4, i1, fast_ok, hint_fast && fast_ok, lane_off, it, r2x4, done,
+                                                                      PERIOD ? A.period_window : 0u, A.exit_from, staged ? A.exit_cost : 0u);
                 bool lost = false, need_any = false;
                 bool alive[NP], need[NP];
 #pragma unroll
@@ -1855,7 +1873,7 @@ tile_lean_kernel(const LaunchArgs A)
                         const T rec4[4] = {o[p].X, o[p].Yd, o[p].cx, o[p].cyd};
                         T rec[NF];
                         for (int k = 0; k < NF; ++k) rec[k] = rec4[k];
-                        writer.append(ring, lane, alive[p], pixel[p], (uint32_t)i1, rec);
+                        writer.append(ring, lane, alive[p], pixel[p], (uint32_t)i_end, rec);
                     }
                 }
                 if (need_any) {
@@ -2171,9 +2189,16 @@ pool_kernel(const LaunchArgs A)
         const uint32_t nactive = (uint32_t)__builtin_popcountll(active);
         /* a wave that can no longer refill is on the critical path of the launch: give it issue priority */
         if (dry) __builtin_amdgcn_s_setprio(3);
-        /* every record has run exactly A.i0 updates, so refilled lanes get the LATEST deadline of the wave
-         * (wclock + max_iter - i0) and the earliest one only changes when it is reached: no reduction here */
-        if (!have_running) { next_deadline = wclock + (uint32_t)(max_iter - A.i0); have_running = true; }
+        /* a record has run AT MOST A.i0 updates (exactly that many unless its trip of the tile pass left early), so no
+         * refilled lane's deadline lies before wclock + max_iter - i0, and that is the latest deadline among the lanes that
+         * ran their A.i0: the earliest one only changes when it is reached -- no reduction here.  (Lanes with fewer updates
+         * behind them have later deadlines: where only such lanes were running, the new ones may come first -- the clock stops
+         * at the bound, finds nobody due and looks for the earliest deadline then.) */
+        {
+            const uint32_t bound = wclock + (uint32_t)(max_iter - A.i0);
+            if (!have_running || (int32_t)(bound - next_deadline) < 0) next_deadline = bound;
+            have_running = true;
+        }
 
         /* ---- iterate until `goal` lanes have finished ---- */
         /* How many idle lanes to wait for.  A retire + refill costs the wave about 40 updates' worth of instructions

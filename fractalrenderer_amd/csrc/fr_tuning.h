@@ -23,6 +23,9 @@
  *   "stream_rotate"      2 = survivor-stream writers rotate over the regions (equal regions), 1 = one region per XCD,
  *                        0 = automatic (= 2)
  *   "tile_pixels"        1 / 2 sub-tiles per trip of the lean tile kernel (0 = 2)
+ *   "tile_exit"          lean tile pass, staged: a trip leaves before b0 once alive x (left + cost) < slots x left; the value
+ *                        is that cost in updates (0 = automatic, 1 = off)
+ *   "tile_exit_from"     ... and not before this many updates (0 = automatic)
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1 (general tile kernel)
  *   "ssaa"               SSAA: 0 = automatic (staged wherever the lean kernels apply and the sample grid has <= 2^29 samples),
  *                        1 = the sample loop of the general tile kernel, 2 = staged wherever it applies

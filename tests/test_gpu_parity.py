@@ -367,6 +367,39 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
             renderer.set_option(k, 0)
 
 
+@pytest.mark.parametrize("name", ["seahorse_0008_f64", "c3_julia_f32_centre0", "ship_f64_ragged_mi2048", "c2_mandel_f64_mi1024_ragged"])
+def test_occupancy_exit_of_the_tile_pass_is_bit_identical(fr, renderer, oracle, name):
+    """A trip of the lean tile pass whose live samples are few hands them to the lane pool before its budget b0 is spent
+    (escape_run_lean, "tile_exit" = the assumed per-record cost of the pool in updates, "tile_exit_from" = not before): the
+    records then carry different update counts, the pool honours each (deadlines, deferred escapes, cycle closing).  Off
+    ("tile_exit" = 1) against: the automatic rule, a rule that leaves as soon as one sample has finished (cost 2, from 16:
+    nearly every record leaves early), one that never fires (4096) -- with and without cycle closing, two budgets, ragged
+    frames, and the general tile kernel as the independent side."""
+    p = CASES[name][0]
+    opts = ("tile_kernel", "tile_exit", "tile_exit_from", "periodicity", "stage_first", "staging", "pool_refill_at")
+    try:
+        for W, H in ((200, 120), (264, 40), (17, 64)):
+            renderer.set_option("staging", 3)
+            renderer.set_option("tile_kernel", 1)
+            base = gpu_render(fr, renderer, p, W, H)
+            renderer.set_option("tile_kernel", 0)
+            for kw in (dict(tile_exit=1), dict(), dict(tile_exit=2, tile_exit_from=16), dict(tile_exit=2, tile_exit_from=16, periodicity=1),
+                       dict(tile_exit=2, tile_exit_from=16, periodicity=-1), dict(tile_exit=8, tile_exit_from=32, stage_first=64),
+                       dict(tile_exit=8, tile_exit_from=16, stage_first=160, periodicity=1), dict(tile_exit=4096),
+                       dict(tile_exit=48, tile_exit_from=48, periodicity=-1), dict(tile_exit=2, tile_exit_from=16, pool_refill_at=1),
+                       dict(tile_exit=3, tile_exit_from=1, stage_first=48, pool_refill_at=64, periodicity=1)):
+                for k in opts[1:]:
+                    if k != "staging":
+                        renderer.set_option(k, kw.get(k, 0))
+                cur = gpu_render(fr, renderer, p, W, H)
+                assert renderer.last_stages() == 2
+                for a, b in zip(base, cur):
+                    assert np.array_equal(a, b), (W, H, kw)
+    finally:
+        for k in opts:
+            renderer.set_option(k, 0)
+
+
 @pytest.mark.parametrize("name", ["seahorse_0008_f64", "c3_julia_f32_centre0", "ship_f64_ragged_mi2048", "julia_c_outside_bailout"])
 def test_lean_tile_kernel_equals_the_general_one(fr, renderer, oracle, name):
     """tile_lean_kernel (coordinate tables, NaN-threshold parking, two sub-tiles per trip) against tile_kernel, and 64
