@@ -23,6 +23,7 @@ using namespace fr;
 static constexpr int kMaxStages = 2;            /* tile pass (+ lane-pool pass) */
 static constexpr size_t kStageWords = (size_t)2 * kMaxShards * kShardStrideWords;   /* one stage: its queue heads, then its stream counters */
 static constexpr size_t kCtrlWords = (size_t)kMaxStages * kStageWords;
+static constexpr size_t kReadyWord = kCtrlWords + (size_t)(kFeedbackShards + 1) * kShardStrideWords;   /* LaunchArgs::pro_ready */
 static constexpr size_t kFeedbackWord = kCtrlWords;            /* behind the stages: Feedback::dev_flag (kFeedbackShards words, 128 B apart) */
 static constexpr uint32_t kProbeEvery = 16;                     /* frames between two looks of a view that closed nothing */
 
@@ -88,6 +89,9 @@ struct fr_ctx {
                                  * own stream (exports, colorize) behind it */
     /* automatic cycle closing of the lane pool (pool_wants_cycle_closing) */
     uint32_t render_seq;        /* renders enqueued on this context */
+    uint32_t prologue_epoch;    /* lean tile passes launched with the in-kernel prologue (lean_prologue): 28 bits */
+    uint32_t tune_prepare;      /* 0 = automatic (the tile pass prepares its own control block and tables, except on a capturing
+                                   stream), 1 = prepare_kernel in a launch of its own */
     uint64_t probe_key;         /* what the context renders (fractal, precision, max_iter, geometry, coarse view) */
     int probe_mode;             /* 0 LOOK: every render's pool looks; 1 SKIP: none does, skip_left to go; 2 WAIT: one look is in
                                  * flight (render probe_seq), nobody else looks until its verdict is back */
@@ -144,8 +148,8 @@ extern "C" int fr_ctx_create(int device_ordinal, fr_ctx** out)
         (e2 = hipEventCreate(&c->ev_begin)) != hipSuccess ||
         (e2 = hipEventCreate(&c->ev_end)) != hipSuccess ||
         (e2 = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming)) != hipSuccess ||
-        (e2 = hipMalloc((void**)&c->d_ctrl, (kCtrlWords + (size_t)(kFeedbackShards + 1) * kShardStrideWords) * sizeof(uint32_t))) != hipSuccess ||
-        (e2 = hipMemset(c->d_ctrl, 0, (kCtrlWords + (size_t)(kFeedbackShards + 1) * kShardStrideWords) * sizeof(uint32_t))) != hipSuccess ||
+        (e2 = hipMalloc((void**)&c->d_ctrl, (kCtrlWords + (size_t)(kFeedbackShards + 2) * kShardStrideWords) * sizeof(uint32_t))) != hipSuccess ||
+        (e2 = hipMemset(c->d_ctrl, 0, (kCtrlWords + (size_t)(kFeedbackShards + 2) * kShardStrideWords) * sizeof(uint32_t))) != hipSuccess ||
         (e2 = hipHostMalloc((void**)&c->overflow_host, 64, hipHostMallocMapped)) != hipSuccess ||
         (e2 = hipHostGetDevicePointer((void**)&c->overflow_dev, c->overflow_host, 0)) != hipSuccess ||
         (e2 = hipMalloc((void**)&c->log2_tab, sizeof(tab))) != hipSuccess ||
@@ -275,6 +279,9 @@ extern "C" int fr_ctx_set_tuning(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "tile_pixels")) {
         if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "tile_pixels must be 0 (automatic), 1 or 2");
         c->tune_tile_pixels = (uint32_t)value;
+    } else if (!strcmp(name, "prepare")) {
+        if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "prepare must be 0 (automatic: inside the lean tile pass) or 1 (a launch of its own)");
+        c->tune_prepare = (uint32_t)value;
     } else if (!strcmp(name, "tile_exit")) {
         if (value < 0 || value > 4096) return fr_set_error(FR_ERR_INVALID_ARG, "tile_exit must be 0 (automatic), 1 (off) or a cost in updates up to 4096");
         c->tune_tile_exit = (uint32_t)value;
@@ -969,7 +976,29 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
 
     /* the frame's device time (fr_ctx_last_kernel_ms) includes the small launch that prepares it */
     if (c->timing) FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
-    if (lean) {
+    /* the lean tile pass prepares its own control block and coordinate tables (lean_prologue: its first workgroups, the others
+     * wait on a word keyed by a per-context epoch) -- except on a capturing stream: a replayed launch would carry a stale epoch */
+    bool in_kernel_prologue = false;
+    if (lean && c->tune_prepare != 1u) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+        in_kernel_prologue = cap == hipStreamCaptureStatusNone;
+    }
+    if (in_kernel_prologue) {
+        if (c->prologue_epoch >= 0x0FFFFFF0u) {                 /* 28 bits: start over behind a cleared word */
+            FR_HIP_TRY(hipMemsetAsync(c->d_ctrl + kReadyWord, 0, sizeof(uint32_t), stream));
+            c->prologue_epoch = 0;
+        }
+        const Feedback fb = feedback_of(c);
+        a.pro_ready = c->d_ctrl + kReadyWord;
+        a.pro_epoch = ++c->prologue_epoch << 4;
+        a.pro_ctrl = c->d_ctrl;
+        a.pro_ctrl_words = (uint32_t)((size_t)nstage * kStageWords);
+        a.pro_fb_flag = fb.dev_flag; a.pro_fb_host = fb.host_word; a.pro_prev_seq = fb.prev_seq;
+        uint32_t n = 8;
+        while (n > grid) n >>= 1;
+        a.pro_n = n ? n : 1u;
+    } else if (lean) {
         hipError_t ep = by_variant(fractal, f64, [&](auto t, auto f) {
             return launch_prepare<decltype(t), decltype(f)::value>(stream, a, c->d_ctrl, (uint32_t)((size_t)nstage * kStageWords), feedback_of(c)); });
         if (ep != hipSuccess) return fr_set_error(FR_ERR_HIP, "prepare kernel launch failed: %s", hipGetErrorString(ep));
@@ -991,6 +1020,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         const uint32_t half = ((uint32_t)bounds[0] / 2u + 15u) / 16u * 16u;
         a.exit_from = (int32_t)(c->tune_tile_exit_from ? c->tune_tile_exit_from : (half > kTileExitFrom ? half : kTileExitFrom));
     }
+    a.out.overflow = c->overflow_dev;                           /* (the prologue's timeout reports through it too) */
     if (staged) {
         a.out.base = (uint8_t*)c->stream_buf;
         a.out.n_blocks = stage_counter(c, 0);
@@ -1022,6 +1052,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     if (staged) {
         a.i0 = bounds[0];
         a.i1 = max_iter;
+        a.pro_ready = nullptr;
         a.in = a.out;                                           /* what the tile pass wrote */
         a.in.n_blocks = stage_counter(c, 0);
         memset(&a.out, 0, sizeof(a.out));                       /* the pool pass runs everything out ... */

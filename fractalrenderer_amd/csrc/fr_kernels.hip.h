@@ -159,6 +159,17 @@ struct LaunchArgs {
     double b2x4_d; float b2x4_f; /* 4 bailout^2 in the kernel's precision */
     uint64_t* diag;              /* optional: 4 words per wave (t_start, t_end, items, dequeues) */
     uint32_t* closed_flag;       /* lane pool, PERIOD: set by a wave that closed a cycle (Feedback::dev_flag) */
+    /* PROLOGUE of the lean tile pass (tile_lean_kernel): what prepare_kernel does in a launch of its own -- control words,
+     * coordinate tables, the previous render's cycle-closing verdict -- done by the first `pro_n` workgroups of the tile pass
+     * itself, everybody else waiting on one word: see lean_prologue_produce().  pro_ready == nullptr: prepare_kernel ran. */
+    uint32_t* pro_ready;         /* (epoch << 4) | preparing workgroups that have finished, of the most recent render */
+    uint32_t pro_epoch;          /* this render's epoch << 4 (per context, increasing) */
+    uint32_t pro_n;              /* preparing workgroups: 1, 2, 4 or 8, <= the grid */
+    uint32_t* pro_ctrl;          /* the control block: its live words (every kShardStrideWords-th of pro_ctrl_words) are zeroed */
+    uint32_t pro_ctrl_words;
+    uint32_t pro_prev_seq;       /* Feedback of the context (dev_flag, host_word, prev_seq) */
+    uint32_t* pro_fb_flag;
+    uint32_t* pro_fb_host;
     fr_palette_table pal;
 };
 
@@ -1412,13 +1423,20 @@ tile_kernel(const LaunchArgs A)
  *   MAP 1  shaders/julia.comp:325, :221-225 (= burning_ship.comp:393, :322-325)
  *                                            uv = pix / res;  p = center + (uv - 0.5) * zoom * (aspect, 1)
  * T narrows center / zoom as the reference narrows them for its fp32 shaders (src/compute_effect_manager.h:85-90). */
-template <typename T, int MAP>
-__global__ void __launch_bounds__(kBlockThreads)
-prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n_ctrl, const Feedback fb)
+/* the W + H table entries i = first, first + stride, ...
+ * THROUGH: the entries are written through to memory (system-scope stores) -- for readers on other XCDs inside the SAME
+ * launch (lean_prologue): the eight L2s of the device are not coherent with each other, ordinary stores stay in the
+ * writer's, and the agent-scope release fence that would publish them writes back EVERYTHING that L2 holds dirty (the
+ * previous frame's pixels: measured, +35 us on every frame). */
+template <bool THROUGH, typename T>
+__device__ __forceinline__ void put_entry(T* p, const T v)
 {
-    forward_feedback(fb);
-    const uint32_t stride = gridDim.x * kBlockThreads, first = blockIdx.x * kBlockThreads + threadIdx.x;
-    for (uint32_t i = first; i < n_ctrl; i += stride) ctrl[i] = 0u;
+    if constexpr (THROUGH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *p = v;
+}
+template <typename T, int MAP, bool THROUGH, class ARGS>
+__device__ __forceinline__ void write_coordinate_tables(ARGS& A, const uint32_t first, const uint32_t stride, const uint32_t end)
+{
     T* __restrict__ xs = reinterpret_cast<T*>(A.xs);
     T* __restrict__ yds = reinterpret_cast<T*>(A.yds);
     if (!xs) return;
@@ -1431,14 +1449,14 @@ prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n
          * the SSAA arm of tile_kernel evaluates them per sample */
         const int aa = A.ssaa;
         const T resx = (T)A.res_w, resy = (T)A.res_h;
-        for (uint32_t i = first; i < (uint32_t)(A.W + A.H); i += stride) {
+        for (uint32_t i = first; i < end; i += stride) {
             const bool col = i < (uint32_t)A.W;
             const int g = col ? (int)i : (int)(i - (uint32_t)A.W);
             const int pq = g / aa, sq = g - pq * aa;                 /* pixel and sample index along this axis */
             if constexpr (MAP == 0) {
                 const T ps = (T)pq + (T)sq / (T)aa;
-                if (col) { const T uvx = (ps - T(0.5) * resx) / resy; xs[g] = center_x + uvx * zoom; }
-                else { const T uvy = (ps - T(0.5) * resy) / resy; yds[g] = T(2) * (center_y + uvy * zoom); }
+                if (col) { const T uvx = (ps - T(0.5) * resx) / resy; put_entry<THROUGH>(&xs[g], (T)(center_x + uvx * zoom)); }
+                else { const T uvy = (ps - T(0.5) * resy) / resy; put_entry<THROUGH>(&yds[g], (T)(T(2) * (center_y + uvy * zoom))); }
             } else {
                 const T pixel_size = T(1) / resx;
                 const T sample_offset = pixel_size / (T)aa;
@@ -1446,38 +1464,114 @@ prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n
                 if (col) {
                     T uvx = (T)pq / resx;
                     uvx = uvx + ((T)sq * sample_offset - centre) / resx;
-                    xs[g] = center_x + (uvx - T(0.5)) * zoom * aspect;
+                    put_entry<THROUGH>(&xs[g], (T)(center_x + (uvx - T(0.5)) * zoom * aspect));
                 } else {
                     T uvy = (T)pq / resy;
                     uvy = uvy + ((T)sq * sample_offset - centre) / resy;
-                    yds[g] = T(2) * (center_y + (uvy - T(0.5)) * zoom);
+                    put_entry<THROUGH>(&yds[g], (T)(T(2) * (center_y + (uvy - T(0.5)) * zoom)));
                 }
             }
         }
         return;
     }
     const T resx = (T)A.W, resy = (T)A.H;
-    for (uint32_t i = first; i < (uint32_t)(A.W + A.H); i += stride) {
+    for (uint32_t i = first; i < end; i += stride) {
         if (i < (uint32_t)A.W) {
             const int px = (int)i;
             if constexpr (MAP == 0) {
                 const T uvx = ((T)px - T(0.5) * resx) / resy;
-                xs[px] = center_x + uvx * zoom;
+                put_entry<THROUGH>(&xs[px], (T)(center_x + uvx * zoom));
             } else {
                 const T uvx = (T)px / resx;
-                xs[px] = center_x + (uvx - T(0.5)) * zoom * aspect;
+                put_entry<THROUGH>(&xs[px], (T)(center_x + (uvx - T(0.5)) * zoom * aspect));
             }
         } else {
             const int py = (int)(i - (uint32_t)A.W);
             if constexpr (MAP == 0) {
                 const T uvy = ((T)py - T(0.5) * resy) / resy;
-                yds[py] = T(2) * (center_y + uvy * zoom);
+                put_entry<THROUGH>(&yds[py], (T)(T(2) * (center_y + uvy * zoom)));
             } else {
                 const T uvy = (T)py / resy;
-                yds[py] = T(2) * (center_y + (uvy - T(0.5)) * zoom);
+                put_entry<THROUGH>(&yds[py], (T)(T(2) * (center_y + (uvy - T(0.5)) * zoom)));
             }
         }
     }
+}
+
+template <typename T, int MAP>
+__global__ void __launch_bounds__(kBlockThreads)
+prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n_ctrl, const Feedback fb)
+{
+    forward_feedback(fb);
+    const uint32_t stride = gridDim.x * kBlockThreads, first = blockIdx.x * kBlockThreads + threadIdx.x;
+    for (uint32_t i = first; i < n_ctrl; i += stride) ctrl[i] = 0u;
+    write_coordinate_tables<T, MAP, false>(A, first, stride, (uint32_t)(A.W + A.H));
+}
+
+/* PROLOGUE of the lean tile pass.  A render used to be prepare_kernel -> tile pass (-> lane pool): a 4.5 us launch and the
+ * ~5 us it takes a dependent kernel to start behind it, in front of EVERY frame -- a fifth of a 1080p frame at max_iter 256
+ * (the reference's interactive default), a quarter of a 512 x 512 one.  Here the first pro_n workgroups of the tile pass do
+ * that work themselves (control words, the W + H coordinates, the feedback word) and publish it: each ends with a release
+ * fence and two atomics on ONE word -- max(word, epoch << 4), then + 1 -- so the word reads (epoch << 4) | pro_n exactly when
+ * all of them are through, whatever an earlier, failed launch left in it.  Every workgroup (the preparing ones too) waits
+ * for that value before its first queue claim.  The control words are written and read by atomics only; the tables are
+ * written through to memory (put_entry) and first read, on any XCD, after the wait.
+ * No deadlock: workgroups start in index order, so the preparing ones are never behind a waiting one; the grid of a
+ * persistent kernel is resident as a whole anyway.  And no unbounded wait: a workgroup that polls for ~50 ms sets the
+ * context's error word (the host fails the render, FR_ERR_INTERNAL) and leaves without touching a queue.
+ * The epoch is the host's per-context render count, so a captured launch cannot be replayed: the host takes the separate
+ * prepare_kernel launch on capturing streams. */
+template <typename T, int MAP>
+__device__ __forceinline__ void lean_prologue_produce()
+{
+    KArgs K = kargs();
+    if (blockIdx.x < K->pro_n) {
+        const uint32_t stride = K->pro_n * kBlockThreads, first = blockIdx.x * kBlockThreads + threadIdx.x;
+        for (uint32_t i = first; i * (uint32_t)kShardStrideWords < K->pro_ctrl_words; i += stride)
+            __hip_atomic_store(K->pro_ctrl + (size_t)i * kShardStrideWords, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            /* a preparing workgroup's entries are a contiguous run of whole 128-byte lines (the tables are one array, xs then
+             * yds): a line written from two XCDs could sit in one's L2 with the other's half stale */
+            const uint32_t n = (uint32_t)(K->W + K->H);
+            const uint32_t chunk = ((n + K->pro_n - 1u) / K->pro_n + 31u) & ~31u;
+            const uint32_t lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+            write_coordinate_tables<T, MAP, true>(*K, lo + threadIdx.x, (uint32_t)kBlockThreads, hi);
+        }
+        /* every store above is a write-through (atomic) store: complete when the counter says so -- no L2 write-back */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_max(K->pro_ready, K->pro_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(K->pro_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        /* the previous render's cycle-closing verdict: nobody in this launch waits for it (its words belong to the lane
+         * pool, a later launch), so it goes behind the publication -- its loads are a round trip to memory */
+        Feedback fb;
+        fb.dev_flag = K->pro_fb_flag; fb.host_word = K->pro_fb_host; fb.prev_seq = K->pro_prev_seq;
+        forward_feedback(fb);                                            /* wave 0 of workgroup 0 */
+    }
+}
+/* ... and the wait, after the workgroup has staged its constants (which the preparing workgroups do while their stores are
+ * on their way) */
+__device__ __forceinline__ bool lean_prologue_wait(const LaunchArgs& A, uint32_t* lds_word)
+{
+    if (threadIdx.x == 0) {
+        const uint32_t target = A.pro_epoch + A.pro_n;
+        uint32_t ok = 1u;
+        for (uint32_t polls = 0; __hip_atomic_load(A.pro_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target; ++polls) {
+            if (polls > (1u << 20)) {                                    /* ~50 ms of s_sleep(8): this is a bug, say so */
+                if (A.out.overflow) __hip_atomic_store(A.out.overflow, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = 0u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        *lds_word = ok;
+    }
+    /* no acquire fence (it would invalidate the whole L2, for every workgroup): no cache of this XCD can hold a line of the
+     * tables -- the launch began with all of them invalidated, and nobody reads a table before this point */
+    __syncthreads();
+    return *lds_word != 0u;
 }
 
 /* ---- staged SSAA: the average of a pixel's samples ------------------------------------------------------------------
@@ -1755,9 +1849,16 @@ tile_lean_kernel(const LaunchArgs A)
     __shared__ LdsBlock S;
     __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
     stage_constants(S, A);
+    /* (behind stage_constants: in front of it, its atomics stand between the argument block and the copy of its palette table
+     * to LDS, the optimiser then keeps that table in scratch -- 176 B per lane, 78 VGPRs for the fp32 kernel) */
+    if (A.pro_ready) lean_prologue_produce<T, FRACTAL == 0 ? 0 : 1>();
     stage_interior<T, FRACTAL>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
+    __shared__ uint32_t pro_ok;
+    if (A.pro_ready) {
+        if (!lean_prologue_wait(A, &pro_ok)) return;
+    }
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t lx = lane & 7u, ly = lane >> 3;

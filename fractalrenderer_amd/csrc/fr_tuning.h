@@ -23,6 +23,9 @@
  *   "stream_rotate"      2 = survivor-stream writers rotate over the regions (equal regions), 1 = one region per XCD,
  *                        0 = automatic (= 2)
  *   "tile_pixels"        1 / 2 sub-tiles per trip of the lean tile kernel (0 = 2)
+ *   "prepare"            1 = control block + coordinate tables in a launch of their own (prepare_kernel) in front of the lean
+ *                        tile pass; 0 = automatic: by the first workgroups of the tile pass itself (lean_prologue), the
+ *                        separate launch only on capturing streams
  *   "tile_exit"          lean tile pass, staged: a trip leaves before b0 once alive x (left + cost) < slots x left; the value
  *                        is that cost in updates (0 = automatic, 1 = off)
  *   "tile_exit_from"     ... and not before this many updates (0 = automatic)

@@ -330,7 +330,7 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
     base = gpu_render(fr, renderer, p, 200, 120)
     assert renderer.last_stages() == 2                     # default: tile pass + lane-pool pass
     opts = ("staging", "stage_first", "stream_run_max", "stream_workgroups_per_cu", "pool_refill_at",
-            "probes", "stream_probes", "stream_rotate", "tile_kernel", "tile_pixels", "shards", "regions")
+            "probes", "stream_probes", "stream_rotate", "tile_kernel", "tile_pixels", "shards", "regions", "prepare")
     try:
         for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
             renderer.set_tuning(wg, run, shape)
@@ -352,7 +352,9 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
                    dict(tile_kernel=1), dict(tile_pixels=1), dict(tile_pixels=2, staging=1), dict(tile_pixels=1, staging=1),
                    dict(shards=64), dict(shards=64, regions=8), dict(shards=8, regions=64), dict(shards=64, staging=1),
                    dict(shards=64, tile_kernel=1),
-                   dict(shards=64, probes=1, stream_probes=1), dict(shards=64, tile_pixels=1, stream_rotate=1)):
+                   dict(shards=64, probes=1, stream_probes=1), dict(shards=64, tile_pixels=1, stream_rotate=1),
+                   # control block + coordinate tables in a launch of their own instead of the tile pass's prologue
+                   dict(prepare=1), dict(prepare=1, staging=1), dict(prepare=1, shards=64, tile_pixels=1)):
             for k, v in kw.items():
                 renderer.set_option(k, v)
             cur = gpu_render(fr, renderer, p, 200, 120)
@@ -1719,6 +1721,51 @@ def test_overflow_of_a_survivor_stream_is_reported_not_swallowed(fr, oracle):
         r.render(st, W, H, nu=nu)
         assert torch.equal(nu, good)
     finally:
+        r.close()
+
+
+def test_tile_pass_prologue_follows_the_viewport_back_to_back(fr):
+    """The lean tile pass prepares its own control block and coordinate tables (lean_prologue_produce: written through to
+    memory by its first workgroups, read by workgroups on every XCD after one wait).  Frames of DIFFERENT views, sizes,
+    precisions and fractals enqueued back to back on one context with no host synchronisation in between -- small ones, whose
+    tables and planes stay in the caches -- must equal the frames of a context that runs prepare_kernel as a launch of its
+    own: a table entry, a queue head or a stream counter left over from the frame before would show."""
+    import torch
+    views = []
+    for k in range(24):
+        W, H = ((64, 64), (200, 120), (256, 256), (136, 72), (512, 304), (1000, 700))[k % 6]
+        kw = dict(center_x=-0.5 + 0.07 * k, center_y=0.01 * (k % 5), zoom=3.0 / (1 + k % 7), max_iterations=(96, 300, 1024, 2048)[k % 4])
+        ft = (fr.FractalType.Mandelbrot, fr.FractalType.JuliaSet, fr.FractalType.BurningShip)[k % 3]
+        if ft == fr.FractalType.JuliaSet:
+            kw.update(center_x=0.02 * k, julia_c_real=-0.8 + 0.01 * k, julia_c_imag=0.156)
+        prec = fr.Precision.F64 if k % 2 else fr.Precision.F32
+        views.append((fr.FractalState(**kw), W, H, ft, prec))
+    planes = lambda W, H, prec: (torch.full((H, W, 4), -3.0, dtype=torch.float32, device="cuda:0"),
+                                 torch.full((H, W), -3.0, dtype=torch.float64 if prec == fr.Precision.F64 else torch.float32, device="cuda:0"),
+                                 torch.full((H, W), -3, dtype=torch.int32, device="cuda:0"))
+    ref = fr.Renderer(0)
+    r = fr.Renderer(0)
+    try:
+        ref.set_option("prepare", 1)
+        want = []
+        for st, W, H, ft, prec in views:
+            rgba, nu, it = planes(W, H, prec)
+            torch.cuda.synchronize()
+            ref.render(st, W, H, fractal_type=ft, precision=prec, rgba=rgba, nu=nu, iter=it)
+            want.append((rgba, nu, it))
+        for rounds in range(3):
+            got = [planes(W, H, prec) for _, W, H, _, prec in views]
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            for (st, W, H, ft, prec), (rgba, nu, it) in zip(views, got):
+                r.render(st, W, H, fractal_type=ft, precision=prec, rgba=rgba, nu=nu, iter=it, sync=False, stream=side.cuda_stream)
+            side.synchronize()
+            r.check()
+            for k, (w, g) in enumerate(zip(want, got)):
+                for a, b in zip(w, g):
+                    assert torch.equal(a, b), (rounds, k)
+    finally:
+        ref.close()
         r.close()
 
 

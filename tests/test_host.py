@@ -584,8 +584,10 @@ def test_hot_kernels_keep_their_register_budget(fr):
         "_ZN2fr11pool_kernelIfLi1ELb0EEEvNS_10LaunchArgsE": (64, 6, 0),    # fp32 Julia lane pool (C3)
         "_ZN2fr11pool_kernelIfLi1ELb1EEEvNS_10LaunchArgsE": (64, 6, 4),    # ... with cycle closing (the default)
         # lean tile kernel, two sub-tiles per trip (the default tile pass): 5 workgroups per CU = 5 waves per SIMD
-        "_ZN2fr16tile_lean_kernelIdLi0ELb0ELi2EEEvNS_10LaunchArgsE": (96, 5, 16),  # fp64 Mandelbrot, staged (C2/C4/C5)
-        "_ZN2fr16tile_lean_kernelIdLi0ELb1ELi2EEEvNS_10LaunchArgsE": (96, 5, 16),  # one-pass frames (C1), cycle closing
+        # (with the prologue in it -- round 4 -- the register allocator settles the fp64 kernel at 80 VGPRs / 17 spilled SGPRs
+        # instead of 92 / 11: its tile pass measured 10 % shorter on C2, 7 % on C5)
+        "_ZN2fr16tile_lean_kernelIdLi0ELb0ELi2EEEvNS_10LaunchArgsE": (96, 5, 20),  # fp64 Mandelbrot, staged (C2/C4/C5)
+        "_ZN2fr16tile_lean_kernelIdLi0ELb1ELi2EEEvNS_10LaunchArgsE": (96, 5, 20),  # one-pass frames (C1), cycle closing
         "_ZN2fr16tile_lean_kernelIfLi1ELb0ELi2EEEvNS_10LaunchArgsE": (64, 6, 0),   # fp32 Julia (C3): 6 workgroups per CU
         "_ZN2fr16tile_lean_kernelIdLi0ELb0ELi1EEEvNS_10LaunchArgsE": (64, 5, 16),   # one sub-tile per trip
         # general tile kernel (SSAA, other sub-tile shapes, strips that are not whole sub-tile rows)
