@@ -15,7 +15,7 @@ r = fr.Renderer(0)
 anchors = {0: [(-0.743643887037151, 0.13182590420533), (-0.1011, 0.9563), (-1.25066, 0.02012), (0.275, 0.0), (-0.5, 0.0), (-1.7497, 0.00001)],
            1: [(0.0, 0.0), (0.3, 0.2), (-0.6, 0.1)], 2: [(-1.755, -0.03), (-0.5, -0.5), (-1.62, -0.002)]}
 opts = ["staging", "pool_refill_at", "probes", "stream_probes", "stream_rotate", "stage_first", "subtile_shape", "workgroups_per_cu", "periodicity",
-        "tile_kernel", "tile_pixels", "tile_exit", "tile_exit_from", "shards", "regions"]
+        "tile_kernel", "tile_pixels", "tile_exit", "tile_exit_from", "prepare", "shards", "regions"]
 bad = 0
 for trial in range(trials):
     fractal = int(rng.integers(0, 3)); prec = int(rng.integers(0, 2))
@@ -50,6 +50,7 @@ for trial in range(trials):
                 regions=int(rng.choice([0, 0, 8, 64])))
     # occupancy exit of the lean tile pass: off, automatic, "as soon as one sample has finished", never
     tune.update(tile_exit=int(rng.choice([0, 0, 1, 2, 8, 4096])), tile_exit_from=int(rng.choice([0, 0, 1, 16, 64])))
+    tune["prepare"] = int(rng.choice([0, 0, 0, 1]))          # the tile pass's own prologue (automatic) / prepare_kernel in front
     for k in opts: r.set_option(k, tune.get(k, 0))
     shard = None
     if trial % 3 == 1:
