@@ -1517,7 +1517,7 @@ prepare_kernel(const LaunchArgs A, uint32_t* __restrict__ ctrl, const uint32_t n
  * for that value before its first queue claim.  The control words are written and read by atomics only; the tables are
  * written through to memory (put_entry) and first read, on any XCD, after the wait.
  * No deadlock: workgroups start in index order, so the preparing ones are never behind a waiting one; the grid of a
- * persistent kernel is resident as a whole anyway.  And no unbounded wait: a workgroup that polls for ~50 ms sets the
+ * persistent kernel is resident as a whole anyway.  And no unbounded wait: a workgroup that polls a million times (of the order of a second) sets the
  * context's error word (the host fails the render, FR_ERR_INTERNAL) and leaves without touching a queue.
  * The epoch is the host's per-context render count, so a captured launch cannot be replayed: the host takes the separate
  * prepare_kernel launch on capturing streams. */
@@ -1559,7 +1559,7 @@ __device__ __forceinline__ bool lean_prologue_wait(const LaunchArgs& A, uint32_t
         const uint32_t target = A.pro_epoch + A.pro_n;
         uint32_t ok = 1u;
         for (uint32_t polls = 0; __hip_atomic_load(A.pro_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target; ++polls) {
-            if (polls > (1u << 20)) {                                    /* ~50 ms of s_sleep(8): this is a bug, say so */
+            if (polls > (1u << 20)) {                                    /* of the order of a second: this is a bug, say so */
                 if (A.out.overflow) __hip_atomic_store(A.out.overflow, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 ok = 0u;
                 break;
