@@ -82,7 +82,7 @@ FR_FRAME_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int32, C.c_void_p)
 class fr_anim_render_options(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("first_frame", C.c_int32), ("frame_count", C.c_int32),
                 ("frame_step", C.c_int32), ("max_iterations_override", C.c_int32), ("fractal_type_override", C.c_int32),
-                ("on_frame_complete", FR_FRAME_CALLBACK), ("user", C.c_void_p)]
+                ("on_frame_complete", FR_FRAME_CALLBACK), ("user", C.c_void_p), ("raw_fd", C.c_int32), ("reserved", C.c_int32)]
 
 
 class fr_keyframe(C.Structure):

@@ -903,6 +903,7 @@ struct AnimWriter {                                       /* one thread: PNG fil
     int status = FR_OK;
     char err[512] = {0};
     const char* folder = nullptr;
+    int raw_fd = 0;                                       /* > 0: packed RGB24 frames to this descriptor instead of PNG files */
     uint32_t W = 0, H = 0;
 
     void loop()
@@ -917,8 +918,12 @@ struct AnimWriter {                                       /* one thread: PNG fil
                 jobs.pop_front();
             }
             char path[4096];
-            int st = fr_frame_path(folder, j.frame, path, sizeof path);
-            if (st == FR_OK) st = fr_write_png(path, W, H, 8, j.rgb8, nullptr, 0, 0);
+            int st;
+            if (raw_fd > 0) st = fr_write_raw_rgb24(raw_fd, j.rgb8, W, H);
+            else {
+                st = fr_frame_path(folder, j.frame, path, sizeof path);
+                if (st == FR_OK) st = fr_write_png(path, W, H, 8, j.rgb8, nullptr, 0, 0);
+            }
             {
                 std::lock_guard<std::mutex> lk(m);
                 if (st != FR_OK && status == FR_OK) { status = st; snprintf(err, sizeof err, "frame %d: %s", j.frame, fr_last_error()); }
@@ -936,7 +941,9 @@ extern "C" int fr_node_render_animation(fr_node* nd, const fr_anim* anim, const 
                                         const char* output_folder, int32_t* frames_written)
 {
     if (frames_written) *frames_written = 0;
-    if (!nd || !anim || !base || !output_folder) return fr_set_error(FR_ERR_INVALID_ARG, "fr_node_render_animation: NULL argument");
+    if (!nd || !anim || !base) return fr_set_error(FR_ERR_INVALID_ARG, "fr_node_render_animation: NULL argument");
+    if (!output_folder && !(opt && opt->raw_fd > 0))
+        return fr_set_error(FR_ERR_INVALID_ARG, "fr_node_render_animation: no output folder and no raw_fd");
     if (frames_in_flight(nd)) return fr_set_error(FR_ERR_INVALID_ARG, "fr_node_render_animation: frames are in flight (fr_node_wait first)");
     fr_anim_info info;
     int st = fr_anim_get_info(anim, &info);
@@ -957,8 +964,10 @@ extern "C" int fr_node_render_animation(fr_node* nd, const fr_anim* anim, const 
         if (st == FR_OK) st = fr_params_validate(&p0, W, H);
         if (st != FR_OK) return st;
     }
-    st = make_dirs(output_folder);
-    if (st != FR_OK) return st;
+    if (o.raw_fd <= 0) {
+        st = make_dirs(output_folder);
+        if (st != FR_OK) return st;
+    }
     if (first >= last) return FR_OK;
 
     DeviceGuard guard;
@@ -970,7 +979,7 @@ extern "C" int fr_node_render_animation(fr_node* nd, const fr_anim* anim, const 
     hipStream_t xs[kMaxParts] = {nullptr};                /* export + copy-back stream per root */
     std::vector<uint8_t*> host_bufs;
     AnimWriter wr;
-    wr.folder = output_folder; wr.W = W; wr.H = H;
+    wr.folder = output_folder; wr.raw_fd = o.raw_fd > 0 ? o.raw_fd : 0; wr.W = W; wr.H = H;
     struct Pending { uint64_t ticket; int32_t frame; int root, set; };
     std::deque<Pending> pending;
     int rc = FR_OK;

@@ -339,20 +339,21 @@ class Node:
     def in_flight(self) -> int:
         return int(self._lib.fr_node_in_flight(self._node))
 
-    def render_animation(self, anim, output_folder: str, *, base: Optional[FractalState] = None,
+    def render_animation(self, anim, output_folder: Optional[str], *, base: Optional[FractalState] = None,
                          fractal_type: FractalType = FractalType.Mandelbrot, precision: Precision = Precision.F32,
                          width: int = 0, height: int = 0, first_frame: int = 0, frame_count: int = 0, frame_step: int = 0,
-                         max_iterations: int = 0, on_frame_complete=None) -> int:
+                         max_iterations: int = 0, on_frame_complete=None, raw_fd: int = 0) -> int:
         """fr_node_render_animation: AnimationRenderer::start_render (src/animation_renderer.cpp:26-152) over the node's
         devices, end to end (render -> 8-bit export on the frame's root -> PNG).  `anim`: an AnimationSystem.  Returns the
-        number of frames written; on_frame_complete(frame, total) returning True cancels."""
+        number of frames written; on_frame_complete(frame, total) returning True cancels.  raw_fd > 0: packed RGB24 frames to
+        that file descriptor (an encoder's stdin) instead of PNG files; output_folder may then be None."""
         p = (base if base is not None else anim.fractal_state).to_params(fractal_type, precision)
         cb = _capi.FR_FRAME_CALLBACK((lambda f, t, _u: 1 if on_frame_complete(f, t) else 0) if on_frame_complete else 0)
         o = _capi.fr_anim_render_options(int(width), int(height), int(first_frame), int(frame_count), int(frame_step),
-                                         int(max_iterations), 0, cb, None)
+                                         int(max_iterations), 0, cb, None, int(raw_fd), 0)
         n = C.c_int32(0)
-        _capi.check(self._lib.fr_node_render_animation(self._node, anim._h, C.byref(p), C.byref(o), os.fsencode(output_folder),
-                                                       C.byref(n)))
+        folder = os.fsencode(output_folder) if output_folder is not None else None
+        _capi.check(self._lib.fr_node_render_animation(self._node, anim._h, C.byref(p), C.byref(o), folder, C.byref(n)))
         return int(n.value)
 
     def rccl_usable(self) -> bool:

@@ -368,6 +368,11 @@ typedef struct fr_anim_render_options {
     int32_t fractal_type_override;        /* 0: base's; else fr_fractal_type + 1 (the engine's current_fractal_type) */
     fr_frame_callback on_frame_complete;  /* may be NULL                                                             */
     void* user;
+    int32_t raw_fd;                       /* > 0: no PNG files -- every frame goes to this file descriptor as packed RGB24,
+                                           * top row first, in frame order (fr_write_raw_rgb24: the stdin of `ffmpeg -f rawvideo
+                                           * -pix_fmt rgb24 -s WxH -framerate F -i -`); the bytes are the PNG files' pixels.
+                                           * output_folder may then be NULL.  0: PNG files (the reference's behaviour)    */
+    int32_t reserved;                     /* 0 */
 } fr_anim_render_options;
 int  fr_node_render_animation(fr_node* node, const fr_anim* anim, const fr_params* base, const fr_anim_render_options* options,
                               const char* output_folder, int32_t* frames_written);

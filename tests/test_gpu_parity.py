@@ -1254,6 +1254,51 @@ def test_node_render_animation_matches_single_gpu_pngs(fr, renderer, tmp_path, n
         assert "at least 2 keyframes" in str(e.value) and not os.path.exists(str(tmp_path / "none"))
 
 
+def test_node_render_animation_into_a_pipe(fr, renderer, tmp_path):
+    """fr_anim_render_options.raw_fd: the frames of an animation as packed RGB24 into a file descriptor -- what an encoder
+    reads from its stdin (`ffmpeg -f rawvideo -pix_fmt rgb24`, src/video_encoder.cpp:195-224) -- instead of PNG files: no
+    deflate between the GPUs and the encoder.  Through an OS pipe with a reader thread; every frame's bytes are the pixels
+    the PNG path writes (fr_export_rgb8 of the post-chained frame, fp16 rounding included), in frame order; no folder is
+    created or needed."""
+    import threading
+    import torch
+    anim = fr.AnimationSystem()
+    assert anim.load_from_file(os.path.join(os.path.dirname(__file__), "golden", "reference_sample.franim"))
+    W, H = 264, 152
+    frames = list(range(100, 2400, 400))
+    rd, wr = os.pipe()
+    got = bytearray()
+
+    def reader():
+        with os.fdopen(rd, "rb") as f:
+            while True:
+                b = f.read(1 << 16)
+                if not b:
+                    break
+                got.extend(b)
+    th = threading.Thread(target=reader)
+    th.start()
+    seen = []
+    try:
+        with fr.Node([0, 0, 0]) as node:
+            wrote = node.render_animation(anim, None, width=W, height=H, first_frame=100, frame_step=400, precision=fr.Precision.F64,
+                                          raw_fd=wr, on_frame_complete=lambda f, t: seen.append(f) and False)
+    finally:
+        os.close(wr)
+        th.join(60)
+    assert wrote == len(frames) and seen == frames
+    assert len(got) == len(frames) * W * H * 3
+    rgba = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for k, f in enumerate(frames):
+        renderer.render(anim.interpolate(anim.frame_time(f)), W, H, precision=fr.Precision.F64, post_chain=True, rgba=rgba)
+        want = renderer.export_rgb8(rgba, W, H, through_half=True).cpu().numpy().tobytes()
+        assert bytes(got[k * W * H * 3:(k + 1) * W * H * 3]) == want, f
+    assert not os.path.exists(str(tmp_path / "anything"))
+    with fr.Node([0]) as node:                                   # neither a folder nor a descriptor: refused
+        with pytest.raises(fr.FractalRendererError):
+            node.render_animation(anim, None, width=W, height=H)
+
+
 def test_randomised_views_match_the_oracle(fr, renderer, oracle):
     """Seeded sweep over the parameter space (fractal, precision, view, iteration budget, bailout, palette,
     frame shape, row-strip shard): escape indices bit-exact, nu and colour within the stated bars.  Views are

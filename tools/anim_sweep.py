@@ -33,5 +33,27 @@ try:
         print(f"  fr_node_render_animation, {parts} part(s) on device 0, {slots} slot(s): {n} frames in {dt:.2f} s = {dt / n * 1e3:.1f} ms/frame "
               f"({size * size * n / dt / 1e6:.0f} Mpx/s end to end, PNG files included, {mb:.1f} MB per file, FR_PNG_LEVEL={os.environ.get('FR_PNG_LEVEL', '6 (default)')}); frame 500 identical: {same}")
         shutil.rmtree(out)
+    # the same frames as packed RGB24 into a file descriptor (fr_anim_render_options.raw_fd: an encoder's stdin) -- here a pipe
+    # whose reader throws the bytes away, and /dev/null: what the devices + the 3 B/pixel copy back deliver without a deflate
+    import threading
+    for slots in (2, 4):
+        for sink in ("pipe", "devnull"):
+            if sink == "pipe":
+                rd, wr = os.pipe()
+                def drain():
+                    with os.fdopen(rd, "rb", buffering=0) as f:
+                        while f.read(1 << 22): pass
+                th = threading.Thread(target=drain); th.start()
+            else:
+                wr = os.open(os.devnull, os.O_WRONLY); th = None
+            with fr.Node([0] * parts) as node:
+                node.set_option("slots", slots)
+                t0 = time.perf_counter()
+                n = node.render_animation(anim, None, width=size, height=size, frame_step=100, precision=fr.Precision.F64, max_iterations=4096, raw_fd=wr)
+                dt = time.perf_counter() - t0
+            os.close(wr)
+            if th: th.join()
+            print(f"  fr_node_render_animation, raw RGB24 into {'a pipe (reader discards)' if sink == 'pipe' else '/dev/null'}, {parts} part(s), {slots} slot(s): "
+                  f"{n} frames in {dt:.2f} s = {dt / n * 1e3:.1f} ms/frame ({size * size * n / dt / 1e6:.0f} Mpx/s end to end)")
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
