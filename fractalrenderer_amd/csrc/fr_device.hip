@@ -72,6 +72,7 @@ struct fr_ctx {
     void* coord_buf;            /* lean tile pass: W + H coordinates of the frame being rendered (prepare_kernel) */
     size_t coord_bytes;
     uint32_t tune_tile_kernel;  /* 0 = automatic (the lean tile kernel where it applies), 1 = the general tile_kernel */
+    uint32_t tune_ssaa_band;    /* staged SSAA: samples per band of a whole frame whose sample grid is larger (0 = automatic: 2^29) */
     uint32_t tune_ssaa;         /* SSAA: 0 = automatic, 1 = the sample loop of the general tile kernel, 2 = staged (sample grid
                                  * through tile pass + lane pool, then ssaa_reduce_kernel) wherever it applies */
     void* ssaa_buf;             /* staged SSAA: the sample planes (colour [+ nu] [+ iter]), grow-only */
@@ -291,6 +292,9 @@ extern "C" int fr_ctx_set_tuning(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "ssaa")) {
         if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "ssaa must be 0 (automatic), 1 (sample loop of the general tile kernel) or 2 (staged)");
         c->tune_ssaa = (uint32_t)value;
+    } else if (!strcmp(name, "ssaa_band_samples")) {
+        if (value < 0 || value > (1ll << 30)) return fr_set_error(FR_ERR_INVALID_ARG, "ssaa_band_samples must be 0 (automatic: 2^29) or up to 2^30");
+        c->tune_ssaa_band = (uint32_t)value;
     } else if (!strcmp(name, "pool_items_per_wg")) {
         if (value < 0 || value > 4096) return fr_set_error(FR_ERR_INVALID_ARG, "pool_items_per_wg must be in [0,4096]");
         c->tune_pool_items_per_wg = (uint32_t)value;
@@ -869,9 +873,36 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
          * grid takes ONE pass -- 1080p at max_iter 256: -38 % -- because the lean kernel beats the general one.  The sample
          * planes and the survivor stream of the sample grid are context scratch: 16 B + up to 60 B per sample; above 2^29
          * samples -- 8192^2 at aa 3 -- the sample loop stays.) */
-        const bool fits = nsamples <= (1ull << 29) || c->tune_ssaa == 2u;
+        const uint64_t band_cap = c->tune_ssaa_band ? c->tune_ssaa_band : (1ull << 29);
+        const bool fits = nsamples <= band_cap || (c->tune_ssaa == 2u && !c->tune_ssaa_band);
         if (lean_ok && fits && nsamples < (1ull << 31) && (uint64_t)norm.rows_per_strip * aa <= 0xFFFFFFFFull)
             return enqueue_ssaa_staged(c, p, W, H, &norm, rows_local, rgba, nu, iter, stream, reserve_only, out_frame);
+        /* A WHOLE frame whose sample grid is larger (a print export: 8192^2 at aa 3 is 6e8 samples, 46 GB of sample planes and
+         * survivor stream) goes through the same scratch band by band: contiguous bands of whole sub-tile rows, each rendered as
+         * the one strip of "part b of B" straight into the caller's planes (FR_LAYOUT_FRAME addressing), one after the other on
+         * the stream.  Same samples, same sums: bit-identical (test_staged_ssaa_in_bands...).  Row-strip shards keep the sample
+         * loop above the cap: a band of a shard is not a shard. */
+        if (lean_ok && !fits && norm.nparts == 1 && !out_frame && (uint64_t)W * aa * 8u * aa <= band_cap) {
+            const uint64_t per_row = (uint64_t)W * aa * aa;                     /* samples per pixel row */
+            uint32_t band_rows = (uint32_t)(band_cap / per_row) & ~7u;           /* whole sub-tile rows, >= 8 by the test above */
+            if (band_rows > H) band_rows = (H + 7u) & ~7u;
+            const uint32_t nbands = (H + band_rows - 1u) / band_rows;
+            const bool timed = c->timing;
+            if (timed && !reserve_only) FR_HIP_TRY(hipEventRecord(c->ev_begin, stream));
+            c->timing = false;                                                   /* one event pair around all bands */
+            int st = FR_OK;
+            for (uint32_t b = 0; b < nbands && st == FR_OK; ++b) {
+                const fr_shard band = {b, nbands, band_rows};
+                st = enqueue_ssaa_staged(c, p, W, H, &band, fr_shard_rows(&band, H), rgba, nu, iter, stream, reserve_only, true);
+                if (reserve_only) break;                                         /* the first band is the largest */
+            }
+            c->timing = timed;
+            if (st == FR_OK && timed && !reserve_only) {
+                FR_HIP_TRY(hipEventRecord(c->ev_end, stream));
+                c->have_timing = true;
+            }
+            return st;
+        }
     }
 
     LaunchArgs a;

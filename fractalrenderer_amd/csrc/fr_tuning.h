@@ -32,6 +32,8 @@
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1 (general tile kernel)
  *   "ssaa"               SSAA: 0 = automatic (staged wherever the lean kernels apply and the sample grid has <= 2^29 samples),
  *                        1 = the sample loop of the general tile kernel, 2 = staged wherever it applies
+ *   "ssaa_band_samples"  staged SSAA of a whole frame: sample grids larger than this go through the scratch in bands of whole
+ *                        sub-tile rows (0 = automatic: 2^29 samples; tests set it small to band small frames)
  *   "debug_region_blocks" caps the capacity of a survivor-stream region so that the overflow report (FR_ERR_INTERNAL)
  *                        can be exercised; 0 = the real capacity (1.5x the worst case)
  */

@@ -1531,6 +1531,15 @@ def test_staged_ssaa_is_bit_identical_to_the_sample_loop(fr, renderer):
                 auto = run(0)
                 for a, b in zip(want, auto):
                     assert torch.equal(a, b), (ft, prec, aa, "auto")
+                # a sample grid larger than the band size goes through the scratch in bands of whole sub-tile rows (print-export
+                # sizes: above 2^29 samples; here the band size is set small: 118 rows in bands of 8, 16, 40, 112 rows)
+                for band in (W * aa * aa * 8, W * aa * aa * 23, W * aa * aa * 40, W * aa * aa * 117):
+                    renderer.set_option("ssaa_band_samples", band)
+                    banded = run(0)
+                    renderer.set_option("ssaa_band_samples", 0)
+                    assert renderer.last_stages() == 2                          # staged, not the sample loop
+                    for a, b in zip(want, banded):
+                        assert torch.equal(a, b), (ft, prec, aa, "bands", band)
                 for part in range(3):                                           # strips of 8 rows: whole sub-tile rows in sample space
                     sh = fr.Shard(part, 3, 8)
                     rows = sh.rows(H)
@@ -1552,6 +1561,7 @@ def test_staged_ssaa_is_bit_identical_to_the_sample_loop(fr, renderer):
             assert torch.equal(got, want)
     finally:
         renderer.set_option("ssaa", 0)
+        renderer.set_option("ssaa_band_samples", 0)
 
 
 def test_bench_node_host_and_default_lines(fr):
