@@ -30,7 +30,8 @@
  *                        is that cost in updates (0 = automatic, 1 = off)
  *   "tile_exit_from"     ... and not before this many updates (0 = automatic)
  *   "subtile_shape"      3: 8x8 pixel sub-tiles per wave, 4: 16x4, 6: 64x1 (general tile kernel)
- *   "ssaa"               SSAA: 0 = automatic (staged wherever the lean kernels apply and the sample grid has <= 2^29 samples),
+ *   "ssaa"               SSAA: 0 = automatic (staged wherever the lean kernels apply; whole frames above 2^29 samples in bands, row-strip
+ *                        shards above it by the sample loop),
  *                        1 = the sample loop of the general tile kernel, 2 = staged wherever it applies
  *   "ssaa_band_samples"  staged SSAA of a whole frame: sample grids larger than this go through the scratch in bands of whole
  *                        sub-tile rows (0 = automatic: 2^29 samples; tests set it small to band small frames)
