@@ -283,6 +283,9 @@ extern "C" int fr_ctx_set_tuning(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "prepare")) {
         if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "prepare must be 0 (automatic: inside the lean tile pass) or 1 (a launch of its own)");
         c->tune_prepare = (uint32_t)value;
+    } else if (!strcmp(name, "debug_prologue_epoch")) {
+        if (value < 0 || value > 0x0FFFFFFF) return fr_set_error(FR_ERR_INVALID_ARG, "debug_prologue_epoch: 28 bits");
+        c->prologue_epoch = (uint32_t)value;          /* tests only: the epoch of the next in-kernel prologue is this + 1 */
     } else if (!strcmp(name, "tile_exit")) {
         if (value < 0 || value > 4096) return fr_set_error(FR_ERR_INVALID_ARG, "tile_exit must be 0 (automatic), 1 (off) or a cost in updates up to 4096");
         c->tune_tile_exit = (uint32_t)value;

@@ -35,6 +35,7 @@
  *                        1 = the sample loop of the general tile kernel, 2 = staged wherever it applies
  *   "ssaa_band_samples"  staged SSAA of a whole frame: sample grids larger than this go through the scratch in bands of whole
  *                        sub-tile rows (0 = automatic: 2^29 samples; tests set it small to band small frames)
+ *   "debug_prologue_epoch" tests only: sets the context's prologue epoch (28 bits), to walk it across its wrap
  *   "debug_region_blocks" caps the capacity of a survivor-stream region so that the overflow report (FR_ERR_INTERNAL)
  *                        can be exercised; 0 = the real capacity (1.5x the worst case)
  */

@@ -1824,6 +1824,44 @@ def test_tile_pass_prologue_follows_the_viewport_back_to_back(fr):
         r.close()
 
 
+def test_tile_pass_prologue_epoch_wraps(fr):
+    """The word the tile pass's workgroups wait on carries a 28-bit epoch (the context's count of such launches); near the end
+    of that range the host clears the word behind the previous render and starts over.  Walked across the wrap here, one
+    frame at a time and back to back: the renders must neither hang nor fail, the frames must be the separate launch's."""
+    import torch
+    W, H = 264, 136
+    st = fr.FractalState(max_iterations=700, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.02)
+    ref = fr.Renderer(0)
+    r = fr.Renderer(0)
+    try:
+        ref.set_option("prepare", 1)
+        want = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+        ref.render(st, W, H, rgba=want)
+        got = torch.empty_like(want)
+        r.render(st, W, H, rgba=got)
+        assert torch.equal(got, want)
+        r.set_option("debug_prologue_epoch", 0x0FFFFFF0 - 3)              # three launches before the host starts over
+        for k in range(8):
+            got.fill_(-1.0)
+            torch.cuda.synchronize()
+            r.render(st, W, H, rgba=got)
+            assert torch.equal(got, want), k
+        # back to back across a second wrap, no host synchronisation in between
+        r.set_option("debug_prologue_epoch", 0x0FFFFFF0 - 5)
+        side = torch.cuda.Stream()
+        outs = [torch.full_like(want, -1.0) for _ in range(12)]
+        torch.cuda.synchronize()
+        for o in outs:
+            r.render(st, W, H, rgba=o, sync=False, stream=side.cuda_stream)
+        side.synchronize()
+        r.check()
+        for k, o in enumerate(outs):
+            assert torch.equal(o, want), k
+    finally:
+        ref.close()
+        r.close()
+
+
 def test_reserved_async_render_is_launch_only(fr, oracle):
     """The header's contract for fr_render_shard_async after fr_ctx_reserve: no allocation, no host synchronisation --
     shown the hard way, by capturing the call into a HIP graph (a hipMalloc / hipFree / stream synchronise inside a
