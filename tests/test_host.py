@@ -7,6 +7,7 @@ import math
 import os
 import re
 import sys
+import subprocess
 
 import numpy as np
 import pytest
@@ -35,6 +36,32 @@ def test_struct_layout_matches_header(fr):
     major, minor = C.c_int(), C.c_int()
     fr.lib().fr_version(C.byref(major), C.byref(minor))
     assert (major.value, minor.value) == (1, 1)       # 1.1: frames in flight on a node
+
+
+def test_ctypes_mirror_matches_the_compiled_header(fr, tmp_path):
+    """sizeof / offsetof of the ABI's structs as a C compiler sees include/fractalrenderer_amd.h, against the ctypes mirror
+    (_capi.py) field by field: a field added on one side only would shift everything behind it silently."""
+    import shutil
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    structs = {"fr_params": fr._capi.fr_params, "fr_output": fr._capi.fr_output, "fr_shard": fr._capi.fr_shard,
+               "fr_anim_render_options": fr._capi.fr_anim_render_options, "fr_keyframe": fr._capi.fr_keyframe}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", "#include \"fractalrenderer_amd.h\"", "int main(void) {"]
+    for name, ct in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c11", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, ct in structs.items():
+        assert int(got[name]) == C.sizeof(ct), name
+        for fname, _ in ct._fields_:
+            assert int(got[f"{name}.{fname}"]) == getattr(ct, fname).offset, (name, fname)
 
 
 def test_no_device_fails_loudly(fr):
