@@ -174,7 +174,7 @@ INTERNAL_SIGNATURES = {
 PUBLIC_OPTIONS = ("periodicity", "staging", "shards", "tile_kernel", "timing", "diag_buffer", "diag_stride")
 TUNING_NAMES = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "stage_first", "pool_refill_at", "stream_run_max",
                 "stream_run_min", "stream_workgroups_per_cu", "probes", "stream_probes", "regions", "stream_rotate",
-                "tile_pixels", "tile_exit", "tile_exit_from", "prepare", "pool_items_per_wg", "subtile_shape", "debug_region_blocks", "debug_prologue_epoch", "ssaa", "ssaa_band_samples")
+                "tile_pixels", "tile_exit", "tile_exit_from", "prepare", "pool_items_per_wg", "subtile_shape", "debug_region_blocks", "debug_prologue_epoch", "ssaa", "ssaa_band_samples", "stripes")
 
 
 class FractalRendererError(RuntimeError):

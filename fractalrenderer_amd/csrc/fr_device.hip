@@ -72,6 +72,8 @@ struct fr_ctx {
     void* coord_buf;            /* lean tile pass: W + H coordinates of the frame being rendered (prepare_kernel) */
     size_t coord_bytes;
     uint32_t tune_tile_kernel;  /* 0 = automatic (the lean tile kernel where it applies), 1 = the general tile_kernel */
+    uint32_t tune_stripes;      /* stripe shading without trap / interior style 2: 0 = automatic (lean tile pass + lane pool, kernel code
+                                   FRACTAL = 3), 1 = the effects variant of the general tile kernel */
     uint32_t tune_ssaa_band;    /* staged SSAA: samples per band of a whole frame whose sample grid is larger (0 = automatic: 2^29) */
     uint32_t tune_ssaa;         /* SSAA: 0 = automatic, 1 = the sample loop of the general tile kernel, 2 = staged (sample grid
                                  * through tile pass + lane pool, then ssaa_reduce_kernel) wherever it applies */
@@ -295,6 +297,9 @@ extern "C" int fr_ctx_set_tuning(fr_ctx* c, const char* name, int64_t value)
     } else if (!strcmp(name, "ssaa")) {
         if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "ssaa must be 0 (automatic), 1 (sample loop of the general tile kernel) or 2 (staged)");
         c->tune_ssaa = (uint32_t)value;
+    } else if (!strcmp(name, "stripes")) {
+        if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "stripes must be 0 (automatic) or 1 (the effects variant of the general tile kernel)");
+        c->tune_stripes = (uint32_t)value;
     } else if (!strcmp(name, "ssaa_band_samples")) {
         if (value < 0 || value > (1ll << 30)) return fr_set_error(FR_ERR_INVALID_ARG, "ssaa_band_samples must be 0 (automatic: 2^29) or up to 2^30");
         c->tune_ssaa_band = (uint32_t)value;
@@ -406,6 +411,20 @@ static hipError_t launch_tile_lean(int np, dim3 grid, hipStream_t s, const Launc
         else
             hipLaunchKernelGGL((tile_lean_kernel<T, FRACTAL, false, 1>), grid, dim3(kBlockThreads), 0, s, a);
     }
+    return hipGetLastError();
+}
+
+/* stripe shading through the lean kernels (kernel code FRACTAL = 3, shade_stripes): two sub-tiles per trip, no cycle closing */
+template <typename T>
+static hipError_t launch_tile_lean_stripes(dim3 grid, hipStream_t s, const LaunchArgs& a)
+{
+    hipLaunchKernelGGL((tile_lean_kernel<T, 3, false, 2>), grid, dim3(kBlockThreads), 0, s, a);
+    return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_pool_stripes(dim3 grid, hipStream_t s, const LaunchArgs& a)
+{
+    hipLaunchKernelGGL((pool_kernel<T, 3, false>), grid, dim3(kBlockThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -857,7 +876,14 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const bool julia = fractal == FR_FRACTAL_JULIA;
     const bool uv_map = fractal != FR_FRACTAL_MANDELBROT;     /* julia.comp:325 / burning_ship.comp:393 viewport map */
     const bool f64 = p->precision == FR_PRECISION_F64;
-    const bool effects = needs_effects(p);
+    /* Stripe shading alone (no orbit trap, no trap-coloured interior) needs nothing along the orbit, only the z of the sample's
+     * last update: such frames take the lean tile pass and the lane pool in their stripe instantiations (kernel code FRACTAL =
+     * 3, shade_stripes) instead of the effects variant's lockstep run to max_iter -- one sample per pixel, 8x8 sub-tiles. */
+    const bool stripes_lean = fractal == FR_FRACTAL_MANDELBROT && p->stripe_enabled && !p->orbit_trap_enabled && p->interior_style != 2 &&
+                              p->antialiasing_samples <= 1 && ssaa_of <= 1 && c->tune_stripes != 1u && c->tune_tile_kernel != 1u &&
+                              (c->tune_shape == 0u || c->tune_shape == 3u) && c->tune_tile_pixels != 1u &&
+                              (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
+    const bool effects = needs_effects(p) && !stripes_lean;
     const int max_iter = p->max_iterations;
 
     /* SSAA.  The sample loop of the general tile kernel runs a pixel's aa x aa samples one after the other, each to max_iter
@@ -946,7 +972,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     c->last_pool_closing = -1;
     /* does this render's lane pool look for cycles?  (fr_ctx_reserve sizes for the pool that looks: the shorter tile pass
      * leaves more survivors.) */
-    const bool pool_looks = staged && (reserve_only ? c->tune_periodicity >= 0 : pool_wants_cycle_closing(c, p, W, rows_local));
+    const bool pool_looks = staged && !stripes_lean &&           /* (a closed cycle has no z after max_iter updates) */
+                            (reserve_only ? c->tune_periodicity >= 0 : pool_wants_cycle_closing(c, p, W, rows_local));
     if (staged && !pool_looks) nstage = plan_stages(c, p, effects, (size_t)rows_local * W, true, bounds);   /* (still two passes) */
     /* survivor-stream writers move to the next region after every block: the regions come out equally
      * long with the same mix of blocks, so the reading pass is balanced with little stealing (measured,
@@ -1072,8 +1099,10 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     } else {
         /* a pass that runs its samples to max_iter closes cycles in escape_run: SSAA (any shape; always compiled in) and
          * the one-sample kernel with 8x8 sub-tiles (its PERIOD instantiation, launch_tile) */
-        a.period_window = !staged ? period_window(c) : 0u;          /* a staged tile pass hands its survivors on */
-        if (lean)
+        a.period_window = !staged && !stripes_lean ? period_window(c) : 0u;   /* a staged tile pass hands its survivors on */
+        if (lean && stripes_lean)
+            e = f64 ? launch_tile_lean_stripes<double>(dim3(grid), stream, a) : launch_tile_lean_stripes<float>(dim3(grid), stream, a);
+        else if (lean)
             e = by_variant(fractal, f64, [&](auto t, auto f) {
                 return launch_tile_lean<decltype(t), decltype(f)::value>(c->tune_tile_pixels == 1u ? 1 : 2, dim3(grid), stream, a); });
         else
@@ -1118,8 +1147,11 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.period_window = pool_looks ? period_window(c) : 0u;
         c->last_pool_closing = a.period_window != 0u;
         a.closed_flag = c->d_ctrl + kFeedbackWord;
-        e = by_variant(fractal, f64, [&](auto t, auto f) {
-            return launch_stream_pool<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
+        if (stripes_lean)
+            e = f64 ? launch_pool_stripes<double>(dim3(sgrid), stream, a) : launch_pool_stripes<float>(dim3(sgrid), stream, a);
+        else
+            e = by_variant(fractal, f64, [&](auto t, auto f) {
+                return launch_stream_pool<decltype(t), decltype(f)::value>(dim3(sgrid), stream, a); });
         if (e != hipSuccess) return fr_set_error(FR_ERR_HIP, "lane-pool kernel launch failed: %s", hipGetErrorString(e));
     }
     if (c->timing) FR_HIP_TRY(hipEventRecord(c->ev_end, stream));

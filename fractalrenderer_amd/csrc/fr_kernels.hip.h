@@ -1413,6 +1413,33 @@ tile_kernel(const LaunchArgs A)
 }
 
 
+/* STRIPE SHADING through the lean tile pass and the lane pool (kernel code FRACTAL = 3: Mandelbrot whose colouring needs the
+ * z of the sample's last update -- shaders/mandelbrot.comp:201-205, stripes without orbit trap and without interior style 2).
+ * The effects variant of the general tile kernel runs such frames in lockstep, one sub-tile at a time, to max_iter; this is
+ * its epilogue restated operation for operation (library log of |z|^2, the division by max_iter, atan2 / sin in the
+ * kernel's precision), so that both routes give the same planes bit for bit.  (ezx, ezy) = z after the escaping update, or
+ * after max_iter updates for a sample that never escaped. */
+template <typename T, class ARGS>
+__device__ __forceinline__ void shade_stripes(ARGS& A, const LdsBlock& S, const int it, const T ezx, const T ezy, T& nu, float rgb[3])
+{
+    const int max_iter = A.max_iter;
+    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+    nu = (T)it;
+    if (it < max_iter) {                                              /* :172-177, as written */
+        const T log_zn = Real<T>::log(ezx * ezx + ezy * ezy) / T(2);
+        const T mu = Real<T>::log(log_zn / Real<T>::ln2()) / Real<T>::ln2();
+        nu = (T)it + T(1) - mu;
+    }
+    T t = nu / (T)max_iter * (T)S.color_scale;                        /* :179 */
+    t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
+    if (it >= max_iter && A.interior_style == 1) return;              /* :182-183: black */
+    palette_eval(A.pal, S.pal, pal_arg(t + (T)S.color_offset), rgb);  /* :190 */
+    const T angle = Real<T>::atan2(ezy, ezx);                          /* :201-205 */
+    const float sv = 0.5f + 0.5f * (float)Real<T>::sin(angle * (T)S.stripe_density + nu * T(0.3));
+    const float m = 0.7f * (1.0f - sv) + 1.3f * sv;
+    rgb[0] *= m; rgb[1] *= m; rgb[2] *= m;
+}
+
 /* ---- control block + coordinate tables ---------------------------------------------------------------------------
  * One small launch in front of every render (replaces clear_words_kernel there): zeroes the queue heads / stream
  * counters and writes the two coordinate tables of the lean tile pass.  The viewport map is separable -- Re c depends on
@@ -1641,11 +1668,12 @@ ssaa_reduce_kernel(const SsaaArgs A)
  * handling, argument re-reads -- is paid once per NP x 64 pixels.  Scalar and vector issue hardly overlap in this code
  * (every few instructions one waits for the other: v_cmp -> branch, exec write -> VALU; measured: VALU and SALU + branch
  * cycles add up to ~85 % of the pass), so halving the scalar work per pixel is worth as much as removing vector work. */
-template <typename T, int NP, bool ABS, bool PERIOD>
+template <typename T, int NP, bool ABS, bool PERIOD, bool ESCZ = false>
 __device__ __forceinline__ int escape_run_lean(Orbit<T> (&o)[NP], const T B2x4, const int i1, const bool fast_ok, bool fast,
                                                const bool (&lane_off)[NP], int (&esc_i)[NP], T (&esc_r2x4)[NP],
                                                uint64_t (&done)[NP], const uint32_t period_window,
-                                               const int exit_from, const uint32_t exit_cost)
+                                               const int exit_from, const uint32_t exit_cost,
+                                               T (*esc_X)[NP] = nullptr, T (*esc_Yd)[NP] = nullptr)   /* ESCZ: z at the escape */
 {
     using Bits = typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type;
     constexpr Bits kNaNBits = sizeof(T) == 8 ? (Bits)0x7FF8000000000000ull : (Bits)0x7FC00000u;
@@ -1745,7 +1773,10 @@ __device__ __forceinline__ int escape_run_lean(Orbit<T> (&o)[NP], const T B2x4, 
                 all = ~0ull;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    if (e[p]) { esc_i[p] = i; esc_r2x4[p] = r2x4[p]; finish(thr[p]); }
+                    if (e[p]) {
+                        esc_i[p] = i; esc_r2x4[p] = r2x4[p]; finish(thr[p]);
+                        if constexpr (ESCZ) { (*esc_X)[p] = o[p].X; (*esc_Yd)[p] = o[p].Yd; }
+                    }
                     done[p] |= m[p];
                     all &= done[p];
                 }
@@ -1845,14 +1876,16 @@ tile_lean_kernel(const LaunchArgs A)
 {
     constexpr int NF = RecFields<FRACTAL>::n;
     constexpr bool ABS = Form<FRACTAL>::abs_step;
+    constexpr bool STRIPES = FRACTAL == 3;                    /* Mandelbrot + stripe shading: see shade_stripes */
+    constexpr int FR = STRIPES ? 0 : FRACTAL;                 /* the fractal proper */
 
     __shared__ LdsBlock S;
     __shared__ WaveRing<T, NF> rings[kWavesPerBlock];
     stage_constants(S, A);
     /* (behind stage_constants: in front of it, its atomics stand between the argument block and the copy of its palette table
      * to LDS, the optimiser then keeps that table in scratch -- 176 B per lane, 78 VGPRs for the fp32 kernel) */
-    if (A.pro_ready) lean_prologue_produce<T, FRACTAL == 0 ? 0 : 1>();
-    stage_interior<T, FRACTAL>(S, A);
+    if (A.pro_ready) lean_prologue_produce<T, FR == 0 ? 0 : 1>();
+    stage_interior<T, FR>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
     __shared__ uint32_t pro_ok;
@@ -1942,7 +1975,7 @@ tile_lean_kernel(const LaunchArgs A)
                     lane_off[p] = !inside[p];
                     pixel[p] = (out_frame ? py0 + ly : lrow) * W + px;       /* where the pixel's planes entries are */
                     const T tx = xs[inside[p] ? px : 0u];
-                    if constexpr (FRACTAL == 1) {
+                    if constexpr (FR == 1) {
                         o[p].X = tx; o[p].Yd = tyd;
                         o[p].cx = (T)S.julia_cx; o[p].cyd = T(2) * (T)S.julia_cy;
                     } else {
@@ -1956,8 +1989,15 @@ tile_lean_kernel(const LaunchArgs A)
                 int it[NP];
                 T r2x4[NP];
                 uint64_t done[NP];
-                const int i_end = escape_run_lean<T, NP, ABS, PERIOD>(o, B2x4, i1, fast_ok, hint_fast && fast_ok, lane_off, it, r2x4, done,
-                                                                      PERIOD ? A.period_window : 0u, A.exit_from, staged ? A.exit_cost : 0u);
+                T esc_X[NP], esc_Yd[NP];                         /* STRIPES: z at the escape */
+                int i_end;
+                if constexpr (STRIPES)
+                    i_end = escape_run_lean<T, NP, ABS, PERIOD, true>(o, B2x4, i1, fast_ok, hint_fast && fast_ok, lane_off, it, r2x4, done,
+                                                                      PERIOD ? A.period_window : 0u, A.exit_from, staged ? A.exit_cost : 0u,
+                                                                      &esc_X, &esc_Yd);
+                else
+                    i_end = escape_run_lean<T, NP, ABS, PERIOD>(o, B2x4, i1, fast_ok, hint_fast && fast_ok, lane_off, it, r2x4, done,
+                                                                PERIOD ? A.period_window : 0u, A.exit_from, staged ? A.exit_cost : 0u);
                 bool lost = false, need_any = false;
                 bool alive[NP], need[NP];
 #pragma unroll
@@ -1985,9 +2025,16 @@ tile_lean_kernel(const LaunchArgs A)
                     float rgb[NP][3];
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
-                        shade<T, FRACTAL>(*K, S, lg, it[p], T(0.25) * r2x4[p], want_nu, want_rgb, nu[p], rgb[p]);
+                        if constexpr (STRIPES) {
+                            /* a sample that never escaped: its z after max_iter updates (one-pass frames; a staged pass hands
+                             * such samples on) */
+                            const bool esc = it[p] < i1;
+                            shade_stripes<T>(*K, S, it[p], esc ? esc_X[p] : o[p].X, T(0.5) * (esc ? esc_Yd[p] : o[p].Yd), nu[p], rgb[p]);
+                        } else {
+                            shade<T, FR>(*K, S, lg, it[p], T(0.25) * r2x4[p], want_nu, want_rgb, nu[p], rgb[p]);
+                        }
                         if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
-                            post_chain(rgb[p], S.brightness, S.saturation, S.contrast, FRACTAL != 0);
+                            post_chain(rgb[p], S.brightness, S.saturation, S.contrast, FR != 0);
                     }
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
@@ -2078,10 +2125,14 @@ pool_kernel(const LaunchArgs A)
 {
     constexpr int NF = RecFields<FRACTAL>::n;
     constexpr size_t kBlockBytes = RingWriter<T, NF>::kBlockBytes;
+    constexpr bool STRIPES = FRACTAL == 3;                /* Mandelbrot + stripe shading (shade_stripes): a finished lane keeps the
+                                                           * z of its last update, and no lane runs past its deadline */
+    constexpr int FR = STRIPES ? 0 : FRACTAL;
+    static_assert(!(STRIPES && PERIOD), "a closed cycle has no z after max_iter updates");
 
     __shared__ LdsBlock S;
     stage_constants(S, A);
-    stage_interior<T, FRACTAL>(S, A);
+    stage_interior<T, FR>(S, A);
     __shared__ double2 log2_lds[sizeof(T) == 8 ? kLog2Entries : 1];
     const LogTab<T> lg = stage_log2<T>(log2_lds, A);
     __shared__ DeferRing<T, NF> defer_rings[kWavesPerBlock];
@@ -2118,6 +2169,7 @@ pool_kernel(const LaunchArgs A)
     uint32_t deadline = 0;
     int esc_i = 0;
     T esc_r2 = T(0);
+    T esc_X = T(0), esc_Yd = T(0);       /* STRIPES: z after the lane's last update (escape, or its max_iter-th) */
     /* PERIOD: the lane's own state at the last snapshot (NaN: none since its refill) and "it came back to it" */
     T refX = __builtin_nan(""), refYd = __builtin_nan("");
     uint32_t cyc = 0;
@@ -2160,14 +2212,17 @@ pool_kernel(const LaunchArgs A)
             const int ri0 = D.i0[slot];
             bool open = have;
             uint32_t ek = 0u;
-            T er = T(0);
+            T er = T(0), eX = T(0), eYd = T(0);
             uint64_t pending = __builtin_amdgcn_ballot_w64(have);
             uint32_t k = 0;
             do {
                 orbit_step<T, Form<FRACTAL>::abs_step>(t);
                 const T r = orbit_r2x4(t);
                 const bool e = open && r > B2x4;
-                if (e) { ek = k; er = r; open = false; }
+                if (e) {
+                    ek = k; er = r; open = false;
+                    if constexpr (STRIPES) { eX = t.X; eYd = t.Yd; }
+                }
                 pending &= ~__builtin_amdgcn_ballot_w64(e);
                 ++k;
             } while (pending != 0ull && k < (uint32_t)max_iter);
@@ -2182,10 +2237,12 @@ pool_kernel(const LaunchArgs A)
                 const T r_r2 = esc ? T(0.25) * er : T(0);
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(*kargs(), S, lg, r_it, r_r2, want_nu, want_rgb, nu, rgb);
+                /* (STRIPES: a stretch never crosses a deadline, so a deferred lane did escape before its max_iter-th update) */
+                if constexpr (STRIPES) shade_stripes<T>(*kargs(), S, r_it, eX, T(0.5) * eYd, nu, rgb);
+                else shade<T, FR>(*kargs(), S, lg, r_it, r_r2, want_nu, want_rgb, nu, rgb);
                 KArgs K = kargs();
                 if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
-                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
+                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FR != 0);
                 if (K->rgba) K->rgba[rpix] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
                 if (K->nu) reinterpret_cast<T*>(K->nu)[rpix] = nu;
                 if (K->iter) K->iter[rpix] = r_it;
@@ -2209,10 +2266,11 @@ pool_kernel(const LaunchArgs A)
             if (fin != 0u) {
                 T nu;
                 float rgb[3];
-                shade<T, FRACTAL>(*kargs(), S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
+                if constexpr (STRIPES) shade_stripes<T>(*kargs(), S, esc_i, esc_X, T(0.5) * esc_Yd, nu, rgb);
+                else shade<T, FR>(*kargs(), S, lg, esc_i, esc_r2, want_nu, want_rgb, nu, rgb);
                 KArgs K = kargs();
                 if (want_rgb && (K->flags & FR_FLAG_POST_CHAIN))
-                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FRACTAL != 0);
+                    post_chain(rgb, S.brightness, S.saturation, S.contrast, FR != 0);
                 if (K->rgba) K->rgba[pixel] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
                 if (K->nu) reinterpret_cast<T*>(K->nu)[pixel] = nu;
                 if (K->iter) K->iter[pixel] = esc_i;
@@ -2324,6 +2382,7 @@ pool_kernel(const LaunchArgs A)
             const bool hit = running && (at_or_past ? (int32_t)(wclock - deadline) >= 0 : deadline == wclock);
             if (hit) {
                 esc_i = max_iter; esc_r2 = T(0); fin = 1u;
+                if constexpr (STRIPES) { esc_X = o.X; esc_Yd = o.Yd; }          /* z after exactly max_iter updates */
                 o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
             }
             const uint32_t nhit = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
@@ -2450,6 +2509,11 @@ pool_kernel(const LaunchArgs A)
                 break;
             }
             if (fast) {
+                if constexpr (STRIPES) {
+                    /* no stretch may cross a deadline: the lane's z must be the one after exactly max_iter updates.  Within the
+                     * longest stretch (64 updates) of the earliest deadline the wave runs tested blocks, which stop at it */
+                    if ((uint32_t)(next_deadline - wclock) < 4u * (uint32_t)kFastBlock) goto tested_stretch;
+                }
                 const T sX = o.X, sYd = o.Yd;
                 /* after 2 (6) clean stretches in a row the wave runs 2 (4) blocks per snapshot / test (a half, a
                  * quarter of that overhead on the long interior runs that dominate deep views); a dirty one resets it */
@@ -2527,6 +2591,7 @@ pool_kernel(const LaunchArgs A)
                 if (ring_full) break;        /* 64 deferred escapes queued: replay them (top of the loop) before more arrive */
                 continue;
             }
+        tested_stretch:
             /* tested stretch: up to the next deadline, at most one block.  The loop carries a countdown and
              * one vector-compare branch; goal and deadline are only looked at where they can change (on an
              * escape event / after the stretch).  On escape-dense views such as the C3 Julia dust the scalar
@@ -2547,6 +2612,7 @@ pool_kernel(const LaunchArgs A)
                         esc_i = (int)(wclock + k - 1u - (deadline - (uint32_t)max_iter));
                         esc_r2 = T(0.25) * r2x4;
                         fin = 1u;
+                        if constexpr (STRIPES) { esc_X = o.X; esc_Yd = o.Yd; }
                         o.X = T(0); o.Yd = T(0); o.cx = T(0); o.cyd = T(0); o.x2 = T(0); o.y2d = T(0);
                     }
                     newly += (uint32_t)__builtin_popcountll(em);

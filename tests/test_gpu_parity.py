@@ -369,6 +369,50 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
             renderer.set_option(k, 0)
 
 
+def test_stripe_shading_through_the_lean_kernels_equals_the_effects_variant(fr, renderer):
+    """Stripe shading without orbit trap / trap-coloured interior needs only the z of a sample's last update: such frames take
+    the lean tile pass and the lane pool in their stripe instantiations (kernel code 3, shade_stripes: the pool keeps every
+    finished lane's z and lets no stretch cross a deadline, so that an interior sample's z is the one after exactly max_iter
+    updates) instead of the effects variant's lockstep run.  Both routes must give the same planes bit for bit: fp64 / fp32,
+    interior styles 0 (striped interior: the z after max_iter updates matters) and 1, one pass and two, post chain, ragged
+    frames, row strips, every pool tuning that moves deadlines and stretches around."""
+    import torch
+    views = [dict(max_iterations=1024), dict(max_iterations=700, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.02),
+             dict(max_iterations=300, zoom=1.5), dict(max_iterations=2000, center_x=-0.1011, center_y=0.9563, zoom=0.05)]
+    opts = ("stripes", "staging", "stage_first", "pool_refill_at", "tile_exit", "tile_exit_from", "shards", "prepare", "stream_run_max")
+    try:
+        for k, kw in enumerate(views):
+            for prec in (fr.Precision.F64, fr.Precision.F32):
+                st = fr.FractalState(stripe_enabled=True, stripe_density=(3.0, 7.5, 12.0, 20.0)[k], interior_style=k % 2,
+                                     color_offset=0.1 * k, color_scale=1.0 + k, palette_mode=k % 6, **kw)
+                nu_dt = torch.float64 if prec == fr.Precision.F64 else torch.float32
+                for W, H in ((264, 152), (131, 67)):
+                    def run(shard=None, rows=H, post=False, **tune):
+                        for o in opts:
+                            renderer.set_option(o, tune.get(o, 0))
+                        out = (torch.full((rows, W, 4), -1.0, dtype=torch.float32, device="cuda"), torch.full((rows, W), -1.0, dtype=nu_dt, device="cuda"),
+                               torch.full((rows, W), -1, dtype=torch.int32, device="cuda"))
+                        torch.cuda.synchronize()
+                        renderer.render(st, W, H, precision=prec, post_chain=post, rgba=out[0], nu=out[1], iter=out[2], shard=shard)
+                        return out
+                    for post in (False, True):
+                        want = run(post=post, stripes=1)
+                        assert renderer.last_stages() == 1                    # the effects variant: one lockstep pass
+                        for tune in (dict(), dict(staging=1), dict(staging=3, stage_first=32), dict(staging=3, stage_first=160, pool_refill_at=1),
+                                     dict(staging=3, pool_refill_at=64, tile_exit=2, tile_exit_from=16), dict(staging=3, shards=64, prepare=1),
+                                     dict(staging=3, stage_first=48, stream_run_max=4)):
+                            got = run(post=post, **tune)
+                            for a, b in zip(want, got):
+                                assert torch.equal(a, b), (k, prec, W, H, post, tune)
+                    sh = fr.Shard(1, 3, 16)
+                    w2, g2 = run(sh, sh.rows(H), stripes=1), run(sh, sh.rows(H), staging=3)
+                    for a, b in zip(w2, g2):
+                        assert torch.equal(a, b), (k, prec, W, H, "strips")
+    finally:
+        for o in opts:
+            renderer.set_option(o, 0)
+
+
 @pytest.mark.parametrize("name", ["seahorse_0008_f64", "c3_julia_f32_centre0", "ship_f64_ragged_mi2048", "c2_mandel_f64_mi1024_ragged"])
 def test_occupancy_exit_of_the_tile_pass_is_bit_identical(fr, renderer, oracle, name):
     """A trip of the lean tile pass whose live samples are few hands them to the lane pool before its budget b0 is spent

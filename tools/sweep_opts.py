@@ -8,7 +8,7 @@ import fractalrenderer_amd as fr
 from bench import WORKLOADS
 ALL = ("workgroups_per_cu", "run_max", "run_min", "shift_bias", "subtile_shape", "staging", "stage_first",
        "stream_run_max", "stream_run_min", "stream_workgroups_per_cu", "pool_refill_at", 
-       "probes", "stream_probes", "stream_rotate", "periodicity", "tile_kernel", "tile_pixels", "tile_exit", "tile_exit_from", "prepare", "shards", "regions")
+       "probes", "stream_probes", "stream_rotate", "periodicity", "tile_kernel", "tile_pixels", "tile_exit", "tile_exit_from", "prepare", "stripes", "shards", "regions")
 name, rounds = sys.argv[1], int(sys.argv[2])
 variants = sys.argv[3:] or [""]
 w = WORKLOADS[name]; W, H = w["W"], w["H"]
