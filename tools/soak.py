@@ -15,7 +15,7 @@ r = fr.Renderer(0)
 anchors = {0: [(-0.743643887037151, 0.13182590420533), (-0.1011, 0.9563), (-1.25066, 0.02012), (0.275, 0.0), (-0.5, 0.0), (-1.7497, 0.00001)],
            1: [(0.0, 0.0), (0.3, 0.2), (-0.6, 0.1)], 2: [(-1.755, -0.03), (-0.5, -0.5), (-1.62, -0.002)]}
 opts = ["staging", "pool_refill_at", "probes", "stream_probes", "stream_rotate", "stage_first", "subtile_shape", "workgroups_per_cu", "periodicity",
-        "tile_kernel", "tile_pixels", "tile_exit", "tile_exit_from", "prepare", "shards", "regions"]
+        "tile_kernel", "tile_pixels", "tile_exit", "tile_exit_from", "prepare", "stripes", "shards", "regions"]
 bad = 0
 for trial in range(trials):
     fractal = int(rng.integers(0, 3)); prec = int(rng.integers(0, 2))
@@ -35,6 +35,8 @@ for trial in range(trials):
         kw.update(orbit_trap_enabled=int(rng.integers(0, 2)), stripe_enabled=int(rng.integers(0, 2)),
                   interior_style=int(rng.choice([0, 1, 2, 3])), orbit_trap_radius=float(np.float32(rng.uniform(0.1, 1.5))),
                   stripe_density=float(np.float32(rng.uniform(1.0, 20.0))))
+        if rng.random() < 0.5:       # stripes alone: the lean kernels' stripe instantiations (Mandelbrot)
+            kw.update(orbit_trap_enabled=0, stripe_enabled=1, interior_style=int(rng.choice([0, 0, 1])))
     if prec == 0:
         kw["aa"] = 1          # fp32 samples next to the palette's fract() wrap legitimately flip; only checkable per pixel
     p = oracle.OracleParams(**kw)
@@ -51,6 +53,7 @@ for trial in range(trials):
     # occupancy exit of the lean tile pass: off, automatic, "as soon as one sample has finished", never
     tune.update(tile_exit=int(rng.choice([0, 0, 1, 2, 8, 4096])), tile_exit_from=int(rng.choice([0, 0, 1, 16, 64])))
     tune["prepare"] = int(rng.choice([0, 0, 0, 1]))          # the tile pass's own prologue (automatic) / prepare_kernel in front
+    tune["stripes"] = int(rng.choice([0, 0, 0, 1]))          # stripe shading through the lean kernels (automatic) / the effects variant
     for k in opts: r.set_option(k, tune.get(k, 0))
     shard = None
     if trial % 3 == 1:
