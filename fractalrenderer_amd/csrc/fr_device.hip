@@ -879,10 +879,10 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     /* Stripe shading alone (no orbit trap, no trap-coloured interior) needs nothing along the orbit, only the z of the sample's
      * last update: such frames take the lean tile pass and the lane pool in their stripe instantiations (kernel code FRACTAL =
      * 3, shade_stripes) instead of the effects variant's lockstep run to max_iter -- one sample per pixel, 8x8 sub-tiles. */
-    const bool stripes_lean = fractal == FR_FRACTAL_MANDELBROT && p->stripe_enabled && !p->orbit_trap_enabled && p->interior_style != 2 &&
-                              p->antialiasing_samples <= 1 && ssaa_of <= 1 && c->tune_stripes != 1u && c->tune_tile_kernel != 1u &&
-                              (c->tune_shape == 0u || c->tune_shape == 3u) && c->tune_tile_pixels != 1u &&
-                              (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
+    const bool stripes_only = fractal == FR_FRACTAL_MANDELBROT && p->stripe_enabled && !p->orbit_trap_enabled && p->interior_style != 2 &&
+                              c->tune_stripes != 1u && c->tune_tile_kernel != 1u && (c->tune_shape == 0u || c->tune_shape == 3u) &&
+                              c->tune_tile_pixels != 1u;
+    const bool stripes_lean = stripes_only && p->antialiasing_samples <= 1 && (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
     const bool effects = needs_effects(p) && !stripes_lean;
     const int max_iter = p->max_iterations;
 
@@ -893,7 +893,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      * kernels' tables), rendered through tile pass + lane pool into scratch planes, and ssaa_reduce_kernel averages.  Same
      * arithmetic per sample, same summation order: bit-identical planes.  Applies where the lean kernels do (no effects,
      * 8x8 sub-tiles, strips of whole sub-tile rows in sample space) and the sample grid is a legal frame (< 2^31 samples). */
-    if (ssaa_of <= 1 && p->antialiasing_samples > 1 && !effects && c->tune_ssaa != 1u) {
+    if (ssaa_of <= 1 && p->antialiasing_samples > 1 && (!needs_effects(p) || stripes_only) && c->tune_ssaa != 1u) {   /* (striped sample
+                                                                  grids too: their samples take the stripe instantiations) */
         const uint32_t aa = (uint32_t)p->antialiasing_samples;
         const uint64_t nsamples = (uint64_t)W * aa * (uint64_t)H * aa;
         const bool lean_ok = c->tune_tile_kernel != 1u && (c->tune_shape == 0u || c->tune_shape == 3u) &&

@@ -408,6 +408,22 @@ def test_stripe_shading_through_the_lean_kernels_equals_the_effects_variant(fr, 
                     w2, g2 = run(sh, sh.rows(H), stripes=1), run(sh, sh.rows(H), staging=3)
                     for a, b in zip(w2, g2):
                         assert torch.equal(a, b), (k, prec, W, H, "strips")
+                # supersampled: the sample loop of the effects variant against the staged sample grid in the stripe instantiations
+                st_aa = fr.FractalState(stripe_enabled=True, stripe_density=(3.0, 7.5, 12.0, 20.0)[k], interior_style=k % 2,
+                                        antialiasing_samples=2 + k % 2, palette_mode=k % 6, **kw)
+                W, H = 136, 72
+                outs = []
+                for stripes in (1, 0):
+                    for o in opts:
+                        renderer.set_option(o, 0)
+                    renderer.set_option("stripes", stripes)
+                    out = (torch.full((H, W, 4), -1.0, dtype=torch.float32, device="cuda"), torch.full((H, W), -1.0, dtype=nu_dt, device="cuda"),
+                           torch.full((H, W), -1, dtype=torch.int32, device="cuda"))
+                    torch.cuda.synchronize()
+                    renderer.render(st_aa, W, H, precision=prec, post_chain=bool(k % 2), rgba=out[0], nu=out[1], iter=out[2])
+                    outs.append(out)
+                for a, b in zip(*outs):
+                    assert torch.equal(a, b), (k, prec, "ssaa")
     finally:
         for o in opts:
             renderer.set_option(o, 0)
