@@ -106,8 +106,8 @@ WORKLOADS = {
                       "(shaders/mandelbrot.comp:163-166,193-198)",
                  fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=512,
                  state=dict(max_iterations=1024, orbit_trap_enabled=True)),
-    "stripes": dict(desc="effects variant: mandelbrot 4096x4096 max_iter=1024 fp64 default viewport, stripe shading "
-                         "(shaders/mandelbrot.comp:201-205)",
+    "stripes": dict(desc="stripe shading: mandelbrot 4096x4096 max_iter=1024 fp64 default viewport "
+                         "(shaders/mandelbrot.comp:201-205; lean tile pass + lane pool in their stripe instantiations)",
                     fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=512,
                     state=dict(max_iterations=1024, stripe_enabled=True)),
     "colorize": dict(desc="fr_colorize_async: colour from the fp64 smooth-count plane of the C2 frame, 4096x4096 "
