@@ -16,6 +16,7 @@
 #include <time.h>
 #include <pthread.h>
 #include <unistd.h>
+#include <signal.h>
 #include <zlib.h>
 
 static void put_be32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
@@ -253,19 +254,40 @@ int fr_write_png(const char* path, uint32_t width, uint32_t height, int32_t bit_
 }
 
 /* one frame of packed RGB24 to a file descriptor (e.g. the stdin pipe of
- * `ffmpeg -f rawvideo -pix_fmt rgb24 -s WxH -r FPS -i - ...`), retrying short writes */
+ * `ffmpeg -f rawvideo -pix_fmt rgb24 -s WxH -r FPS -i - ...`), retrying short writes.
+ * An encoder that has died must come back as FR_ERR_IO, not as the SIGPIPE that would end the caller's process: the signal is
+ * blocked in the writing thread for the duration of the call, and one that the write raised is taken off the thread's
+ * pending set before the mask is restored (it is thread-directed; a caller that had it blocked or pending already keeps
+ * exactly what it had). */
 int fr_write_raw_rgb24(int fd, const uint8_t* rgb8, uint32_t width, uint32_t height)
 {
     if (fd < 0 || !rgb8 || width == 0 || height == 0) return fr_set_error(FR_ERR_INVALID_ARG, "fr_write_raw_rgb24: bad argument");
+    sigset_t pipe_set, old_set, pending;
+    sigemptyset(&pipe_set);
+    sigaddset(&pipe_set, SIGPIPE);
+    sigpending(&pending);
+    const int was_pending = sigismember(&pending, SIGPIPE) == 1;
+    const int masked = pthread_sigmask(SIG_BLOCK, &pipe_set, &old_set) == 0;
+    int st = FR_OK, err = 0;
     size_t left = (size_t)width * height * 3;
     while (left) {
         const ssize_t n = write(fd, rgb8, left);
         if (n < 0) {
             if (errno == EINTR) continue;
-            return fr_set_error(FR_ERR_IO, "write to fd %d failed: %s", fd, strerror(errno));
+            err = errno;
+            st = FR_ERR_IO;
+            break;
         }
         rgb8 += n; left -= (size_t)n;
     }
+    if (masked) {
+        if (err == EPIPE && !was_pending) {
+            const struct timespec zero = {0, 0};
+            while (sigtimedwait(&pipe_set, NULL, &zero) < 0 && errno == EINTR) {}
+        }
+        (void)pthread_sigmask(SIG_SETMASK, &old_set, NULL);
+    }
+    if (st != FR_OK) return fr_set_error(FR_ERR_IO, "write to fd %d failed: %s", fd, strerror(err));
     return FR_OK;
 }
 

@@ -1357,6 +1357,20 @@ def test_node_render_animation_into_a_pipe(fr, renderer, tmp_path):
     with fr.Node([0]) as node:                                   # neither a folder nor a descriptor: refused
         with pytest.raises(fr.FractalRendererError):
             node.render_animation(anim, None, width=W, height=H)
+        # an encoder that has gone away: the export stops with an I/O error (no hang, nothing left in flight), and the node
+        # renders on afterwards
+        rd, wr = os.pipe()
+        os.close(rd)
+        try:
+            with pytest.raises(fr.FractalRendererError) as e:
+                node.render_animation(anim, None, width=W, height=H, first_frame=100, frame_step=400, precision=fr.Precision.F64, raw_fd=wr)
+            assert e.value.status == fr._capi.FR_ERR_IO and node.in_flight() == 0
+        finally:
+            os.close(wr)
+        out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+        node.render(anim.interpolate(anim.frame_time(100)), W, H, precision=fr.Precision.F64, post_chain=True, rgba=out)
+        renderer.render(anim.interpolate(anim.frame_time(100)), W, H, precision=fr.Precision.F64, post_chain=True, rgba=rgba)
+        assert torch.equal(out, rgba)
 
 
 def test_randomised_views_match_the_oracle(fr, renderer, oracle):

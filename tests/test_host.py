@@ -64,6 +64,46 @@ def test_ctypes_mirror_matches_the_compiled_header(fr, tmp_path):
             assert int(got[f"{name}.{fname}"]) == getattr(ct, fname).offset, (name, fname)
 
 
+def test_raw_frame_writer_survives_a_dead_reader(fr):
+    """fr_write_raw_rgb24 feeds an encoder's stdin.  Whole frames arrive byte for byte through a pipe (short writes retried);
+    a reader that has gone away must come back as FR_ERR_IO -- not as the SIGPIPE that would end the host process (run in a
+    child process with the default disposition, which Python itself does not have) -- and leave no signal pending."""
+    code = r"""
+import ctypes as C, os, signal, sys, threading
+sys.path.insert(0, %r)
+import numpy as np
+import fractalrenderer_amd as fr
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)
+L = fr.lib()
+L.fr_write_raw_rgb24.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]
+W, H = 640, 400
+frame = (np.arange(W * H * 3, dtype=np.uint32) * 2654435761 >> 13).astype(np.uint8)
+rd, wr = os.pipe()
+got = bytearray()
+def reader():
+    with os.fdopen(rd, "rb") as f:
+        while True:
+            b = f.read(4096)
+            if not b: break
+            got.extend(b)
+t = threading.Thread(target=reader); t.start()
+assert L.fr_write_raw_rgb24(wr, frame.ctypes.data, W, H) == 0
+os.close(wr); t.join()
+assert bytes(got) == frame.tobytes()
+rd, wr = os.pipe()
+os.close(rd)                                   # the encoder died
+st = L.fr_write_raw_rgb24(wr, frame.ctypes.data, W, H)
+assert st == fr._capi.FR_ERR_IO, st
+assert signal.SIGPIPE not in signal.sigpending()
+st = L.fr_write_raw_rgb24(wr, frame.ctypes.data, W, H)       # and again
+assert st == fr._capi.FR_ERR_IO, st
+os.close(wr)
+print("alive")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("alive"), (out.returncode, out.stderr[-2000:])
+
+
 def test_no_device_fails_loudly(fr):
     """The product path has no CPU fallback: without a GPU the context cannot be created."""
     import torch
