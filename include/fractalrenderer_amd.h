@@ -434,7 +434,8 @@ int fr_write_png(const char* path, uint32_t width, uint32_t height, int32_t bit_
                  const fr_png_text* texts, int32_t ntexts, int32_t print_metadata);
 
 /* One packed RGB24 frame to a file descriptor (the stdin pipe of an encoder such as
- * `ffmpeg -f rawvideo -pix_fmt rgb24 -s WxH -i -`, src/video_encoder.cpp:195-224), retrying short writes. */
+ * `ffmpeg -f rawvideo -pix_fmt rgb24 -s WxH -i -`, src/video_encoder.cpp:195-224), retrying short writes.  A reader that
+ * has gone away is FR_ERR_IO: SIGPIPE is blocked in the calling thread for the duration of the call. */
 int fr_write_raw_rgb24(int fd, const uint8_t* rgb8, uint32_t width, uint32_t height);
 
 /* "<folder>/frame_%06d.png", src/animation_renderer.cpp:86-88 */
