@@ -102,8 +102,9 @@ WORKLOADS = {
                      fractal="Deep_Zoom", precision="F32", W=4096, H=4096, cpu_rows=256, flops_per_update=23,
                      state=dict(max_iterations=2000, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=1e-6,
                                 use_perturbation=True)),
-    "trap": dict(desc="effects variant: mandelbrot 4096x4096 max_iter=1024 fp64 default viewport, orbit trap blend "
-                      "(shaders/mandelbrot.comp:163-166,193-198)",
+    "trap": dict(desc="orbit trap blend: mandelbrot 4096x4096 max_iter=1024 fp64 default viewport "
+                      "(shaders/mandelbrot.comp:163-166,193-198; lean tile pass + lane pool in their code-3 instantiations: the "
+                      "trap's minimum is the constant 0 as the shader is written)",
                  fractal="Mandelbrot", precision="F64", W=4096, H=4096, cpu_rows=512,
                  state=dict(max_iterations=1024, orbit_trap_enabled=True)),
     "stripes": dict(desc="stripe shading: mandelbrot 4096x4096 max_iter=1024 fp64 default viewport "

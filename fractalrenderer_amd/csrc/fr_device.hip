@@ -876,10 +876,12 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     const bool julia = fractal == FR_FRACTAL_JULIA;
     const bool uv_map = fractal != FR_FRACTAL_MANDELBROT;     /* julia.comp:325 / burning_ship.comp:393 viewport map */
     const bool f64 = p->precision == FR_PRECISION_F64;
-    /* Stripe shading alone (no orbit trap, no trap-coloured interior) needs nothing along the orbit, only the z of the sample's
-     * last update: such frames take the lean tile pass and the lane pool in their stripe instantiations (kernel code FRACTAL =
-     * 3, shade_stripes) instead of the effects variant's lockstep run to max_iter -- one sample per pixel, 8x8 sub-tiles. */
-    const bool stripes_only = fractal == FR_FRACTAL_MANDELBROT && p->stripe_enabled && !p->orbit_trap_enabled && p->interior_style != 2 &&
+    /* The Mandelbrot shader's effects need nothing along the orbit: stripe shading reads the z of the sample's last update, and
+     * the orbit trap's minimum is the constant 0 (see shade_stripes: the first update makes z = c, and distToC is part of
+     * the minimum).  Such frames take the lean tile pass and the lane pool in their code-3 instantiations instead of the
+     * effects variant's lockstep run to max_iter with four running minima -- 8x8 sub-tiles, two per trip.  (Burning Ship's
+     * trap and stripe sums are real accumulators: the effects variant keeps them.) */
+    const bool stripes_only = fractal == FR_FRACTAL_MANDELBROT && needs_effects(p) &&
                               c->tune_stripes != 1u && c->tune_tile_kernel != 1u && (c->tune_shape == 0u || c->tune_shape == 3u) &&
                               c->tune_tile_pixels != 1u;
     const bool stripes_lean = stripes_only && p->antialiasing_samples <= 1 && (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);

@@ -1413,16 +1413,23 @@ tile_kernel(const LaunchArgs A)
 }
 
 
-/* STRIPE SHADING through the lean tile pass and the lane pool (kernel code FRACTAL = 3: Mandelbrot whose colouring needs the
- * z of the sample's last update -- shaders/mandelbrot.comp:201-205, stripes without orbit trap and without interior style 2).
- * The effects variant of the general tile kernel runs such frames in lockstep, one sub-tile at a time, to max_iter; this is
- * its epilogue restated operation for operation (library log of |z|^2, the division by max_iter, atan2 / sin in the
- * kernel's precision), so that both routes give the same planes bit for bit.  (ezx, ezy) = z after the escaping update, or
- * after max_iter updates for a sample that never escaped. */
+/* MANDELBROT EFFECTS through the lean tile pass and the lane pool (kernel code FRACTAL = 3): orbit trap, trap-coloured
+ * interior, stripe shading -- shaders/mandelbrot.comp:182-205.  The effects variant of the general tile kernel runs such
+ * frames in lockstep, one sub-tile at a time, to max_iter, with four running minima per sample; this is its epilogue
+ * restated operation for operation (library log of |z|^2, the division by max_iter, atan2 / sin in the kernel's precision),
+ * so that both routes give the same planes bit for bit.
+ *   STRIPES need the z of the sample's last update: (ezx, ezy) = z after the escaping update, or after max_iter updates for
+ *   a sample that never escaped (the lean kernels' code-3 instantiations carry it).
+ *   The ORBIT TRAP needs nothing: as the shader is written (:153-166) z starts at 0, the first update makes z = c exactly
+ *   (0 * 0 - 0 * 0 + c.x), and the trap takes its minimum AFTER the update, over distToOrigin, distToAxes and
+ *   distToC = length(z - c) -- which is 0 at i = 0, for every sample, in any precision.  minTrap is the constant 0 (the
+ *   general kernel's four running minima compute exactly that, at 10 of its 16 instructions per update), the trap blend
+ *   is a constant mix and the trap-coloured interior a constant colour. */
 template <typename T, class ARGS>
 __device__ __forceinline__ void shade_stripes(ARGS& A, const LdsBlock& S, const int it, const T ezx, const T ezy, T& nu, float rgb[3])
 {
     const int max_iter = A.max_iter;
+    const T min_trap = T(0);                                           /* :163-166, see above */
     rgb[0] = rgb[1] = rgb[2] = 0.0f;
     nu = (T)it;
     if (it < max_iter) {                                              /* :172-177, as written */
@@ -1432,12 +1439,29 @@ __device__ __forceinline__ void shade_stripes(ARGS& A, const LdsBlock& S, const 
     }
     T t = nu / (T)max_iter * (T)S.color_scale;                        /* :179 */
     t = t < T(0) ? T(0) : (t > T(1) ? T(1) : t);
-    if (it >= max_iter && A.interior_style == 1) return;              /* :182-183: black */
+    if (it >= max_iter) {                                             /* :182-188 */
+        if (A.interior_style == 1) return;                            /* black */
+        if (A.interior_style == 2) {
+            const float tf = expf(-(float)min_trap * 6.0f / fmaxf(S.trap_radius, 1e-6f));
+            palette_eval(A.pal, S.pal, S.color_offset + tf * 0.3f, rgb);
+            return;
+        }
+    }
     palette_eval(A.pal, S.pal, pal_arg(t + (T)S.color_offset), rgb);  /* :190 */
-    const T angle = Real<T>::atan2(ezy, ezx);                          /* :201-205 */
-    const float sv = 0.5f + 0.5f * (float)Real<T>::sin(angle * (T)S.stripe_density + nu * T(0.3));
-    const float m = 0.7f * (1.0f - sv) + 1.3f * sv;
-    rgb[0] *= m; rgb[1] *= m; rgb[2] *= m;
+    if (A.trap_enabled) {                                             /* :193-198 */
+        const float r = fmaxf(S.trap_radius, 1e-6f);
+        const float tf = expf(-(float)min_trap * 4.0f / r);
+        const float k = clamp01(tf * 0.8f);
+        rgb[0] = rgb[0] * (1.0f - k) + 1.0f * k;
+        rgb[1] = rgb[1] * (1.0f - k) + 0.8f * k;
+        rgb[2] = rgb[2] * (1.0f - k) + 0.4f * k;
+    }
+    if (A.stripe_enabled) {                                           /* :201-205 */
+        const T angle = Real<T>::atan2(ezy, ezx);
+        const float sv = 0.5f + 0.5f * (float)Real<T>::sin(angle * (T)S.stripe_density + nu * T(0.3));
+        const float m = 0.7f * (1.0f - sv) + 1.3f * sv;
+        rgb[0] *= m; rgb[1] *= m; rgb[2] *= m;
+    }
 }
 
 /* ---- control block + coordinate tables ---------------------------------------------------------------------------
@@ -2510,9 +2534,11 @@ pool_kernel(const LaunchArgs A)
             }
             if (fast) {
                 if constexpr (STRIPES) {
-                    /* no stretch may cross a deadline: the lane's z must be the one after exactly max_iter updates.  Within the
-                     * longest stretch (64 updates) of the earliest deadline the wave runs tested blocks, which stop at it */
-                    if ((uint32_t)(next_deadline - wclock) < 4u * (uint32_t)kFastBlock) goto tested_stretch;
+                    /* where the z of a sample that never escapes is read (striped interior, style 0) no stretch may cross a
+                     * deadline: that z must be the one after exactly max_iter updates.  Within the longest stretch (64 updates)
+                     * of the earliest deadline the wave runs tested blocks, which stop at it */
+                    if (A.stripe_enabled && A.interior_style == 0 &&
+                        (uint32_t)(next_deadline - wclock) < 4u * (uint32_t)kFastBlock) goto tested_stretch;
                 }
                 const T sX = o.X, sYd = o.Yd;
                 /* after 2 (6) clean stretches in a row the wave runs 2 (4) blocks per snapshot / test (a half, a

@@ -369,61 +369,72 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
             renderer.set_option(k, 0)
 
 
-def test_stripe_shading_through_the_lean_kernels_equals_the_effects_variant(fr, renderer):
-    """Stripe shading without orbit trap / trap-coloured interior needs only the z of a sample's last update: such frames take
-    the lean tile pass and the lane pool in their stripe instantiations (kernel code 3, shade_stripes: the pool keeps every
-    finished lane's z and lets no stretch cross a deadline, so that an interior sample's z is the one after exactly max_iter
-    updates) instead of the effects variant's lockstep run.  Both routes must give the same planes bit for bit: fp64 / fp32,
-    interior styles 0 (striped interior: the z after max_iter updates matters) and 1, one pass and two, post chain, ragged
-    frames, row strips, every pool tuning that moves deadlines and stretches around."""
+def test_mandelbrot_effects_through_the_lean_kernels_equal_the_effects_variant(fr, renderer):
+    """The Mandelbrot shader's effects need nothing along the orbit.  Stripe shading reads the z of a sample's last update; the
+    orbit trap's minimum is the constant 0 as the shader is written (z = c exactly after the first update, and length(z - c) is
+    part of the minimum: shaders/mandelbrot.comp:153-166), so the trap blend is a constant mix and the trap-coloured interior
+    a constant colour.  Such frames take the lean tile pass and the lane pool in their code-3 instantiations (shade_stripes:
+    the pool keeps every finished lane's z and, where a striped interior reads it, lets no stretch cross a deadline) instead
+    of the effects variant's lockstep run with four running minima.  Both routes must give the same planes bit for bit:
+    stripes alone / with the orbit trap / the trap alone / the trap-coloured interior, fp64 / fp32, one pass and two, post
+    chain, ragged frames, row strips, supersampled, every pool tuning that moves deadlines and stretches around."""
     import torch
     views = [dict(max_iterations=1024), dict(max_iterations=700, center_x=-0.743643887037151, center_y=0.13182590420533, zoom=0.02),
              dict(max_iterations=300, zoom=1.5), dict(max_iterations=2000, center_x=-0.1011, center_y=0.9563, zoom=0.05)]
     opts = ("stripes", "staging", "stage_first", "pool_refill_at", "tile_exit", "tile_exit_from", "shards", "prepare", "stream_run_max")
+    tunes = (dict(), dict(staging=1), dict(staging=3, stage_first=32), dict(staging=3, stage_first=160, pool_refill_at=1),
+             dict(staging=3, pool_refill_at=64, tile_exit=2, tile_exit_from=16), dict(staging=3, shards=64, prepare=1),
+             dict(staging=3, stage_first=48, stream_run_max=4))
+
+    def planes(rows, W, nu_dt):
+        out = (torch.full((rows, W, 4), -1.0, dtype=torch.float32, device="cuda"), torch.full((rows, W), -1.0, dtype=nu_dt, device="cuda"),
+               torch.full((rows, W), -1, dtype=torch.int32, device="cuda"))
+        torch.cuda.synchronize()
+        return out
+
     try:
         for k, kw in enumerate(views):
             for prec in (fr.Precision.F64, fr.Precision.F32):
-                st = fr.FractalState(stripe_enabled=True, stripe_density=(3.0, 7.5, 12.0, 20.0)[k], interior_style=k % 2,
-                                     color_offset=0.1 * k, color_scale=1.0 + k, palette_mode=k % 6, **kw)
                 nu_dt = torch.float64 if prec == fr.Precision.F64 else torch.float32
-                for W, H in ((264, 152), (131, 67)):
-                    def run(shard=None, rows=H, post=False, **tune):
+                for combo in range(4):
+                    eff = (dict(stripe_enabled=True, interior_style=k % 2),
+                           dict(stripe_enabled=True, orbit_trap_enabled=True, interior_style=k % 2),
+                           dict(orbit_trap_enabled=True, orbit_trap_radius=0.2 + 0.3 * k, interior_style=(k + 1) % 2),
+                           dict(interior_style=2, orbit_trap_radius=0.1 + 0.2 * k, stripe_enabled=bool(k % 2)))[combo]
+                    st = fr.FractalState(stripe_density=(3.0, 7.5, 12.0, 20.0)[k], color_offset=0.1 * k, color_scale=1.0 + k,
+                                         palette_mode=k % 6, **eff, **kw)
+                    for W, H in ((264, 152), (131, 67))[:2 if combo == 0 else 1]:
+                        def run(shard=None, rows=H, post=False, **tune):
+                            for o in opts:
+                                renderer.set_option(o, tune.get(o, 0))
+                            out = planes(rows, W, nu_dt)
+                            renderer.render(st, W, H, precision=prec, post_chain=post, rgba=out[0], nu=out[1], iter=out[2], shard=shard)
+                            return out
+                        for post in (False, True):
+                            want = run(post=post, stripes=1)
+                            assert renderer.last_stages() == 1                    # the effects variant: one lockstep pass
+                            for tune in (tunes if combo == 0 else tunes[:3]):
+                                got = run(post=post, **tune)
+                                for a, b in zip(want, got):
+                                    assert torch.equal(a, b), (k, prec, combo, W, H, post, tune)
+                        sh = fr.Shard(1, 3, 16)
+                        w2, g2 = run(sh, sh.rows(H), stripes=1), run(sh, sh.rows(H), staging=3)
+                        for a, b in zip(w2, g2):
+                            assert torch.equal(a, b), (k, prec, combo, W, H, "strips")
+                    # supersampled: the sample loop of the effects variant against the staged sample grid in the code-3 instantiations
+                    st_aa = fr.FractalState(stripe_density=(3.0, 7.5, 12.0, 20.0)[k], antialiasing_samples=2 + k % 2, palette_mode=k % 6,
+                                            **eff, **kw)
+                    W, H = 136, 72
+                    outs = []
+                    for stripes in (1, 0):
                         for o in opts:
-                            renderer.set_option(o, tune.get(o, 0))
-                        out = (torch.full((rows, W, 4), -1.0, dtype=torch.float32, device="cuda"), torch.full((rows, W), -1.0, dtype=nu_dt, device="cuda"),
-                               torch.full((rows, W), -1, dtype=torch.int32, device="cuda"))
-                        torch.cuda.synchronize()
-                        renderer.render(st, W, H, precision=prec, post_chain=post, rgba=out[0], nu=out[1], iter=out[2], shard=shard)
-                        return out
-                    for post in (False, True):
-                        want = run(post=post, stripes=1)
-                        assert renderer.last_stages() == 1                    # the effects variant: one lockstep pass
-                        for tune in (dict(), dict(staging=1), dict(staging=3, stage_first=32), dict(staging=3, stage_first=160, pool_refill_at=1),
-                                     dict(staging=3, pool_refill_at=64, tile_exit=2, tile_exit_from=16), dict(staging=3, shards=64, prepare=1),
-                                     dict(staging=3, stage_first=48, stream_run_max=4)):
-                            got = run(post=post, **tune)
-                            for a, b in zip(want, got):
-                                assert torch.equal(a, b), (k, prec, W, H, post, tune)
-                    sh = fr.Shard(1, 3, 16)
-                    w2, g2 = run(sh, sh.rows(H), stripes=1), run(sh, sh.rows(H), staging=3)
-                    for a, b in zip(w2, g2):
-                        assert torch.equal(a, b), (k, prec, W, H, "strips")
-                # supersampled: the sample loop of the effects variant against the staged sample grid in the stripe instantiations
-                st_aa = fr.FractalState(stripe_enabled=True, stripe_density=(3.0, 7.5, 12.0, 20.0)[k], interior_style=k % 2,
-                                        antialiasing_samples=2 + k % 2, palette_mode=k % 6, **kw)
-                W, H = 136, 72
-                outs = []
-                for stripes in (1, 0):
-                    for o in opts:
-                        renderer.set_option(o, 0)
-                    renderer.set_option("stripes", stripes)
-                    out = (torch.full((H, W, 4), -1.0, dtype=torch.float32, device="cuda"), torch.full((H, W), -1.0, dtype=nu_dt, device="cuda"),
-                           torch.full((H, W), -1, dtype=torch.int32, device="cuda"))
-                    torch.cuda.synchronize()
-                    renderer.render(st_aa, W, H, precision=prec, post_chain=bool(k % 2), rgba=out[0], nu=out[1], iter=out[2])
-                    outs.append(out)
-                for a, b in zip(*outs):
-                    assert torch.equal(a, b), (k, prec, "ssaa")
+                            renderer.set_option(o, 0)
+                        renderer.set_option("stripes", stripes)
+                        out = planes(H, W, nu_dt)
+                        renderer.render(st_aa, W, H, precision=prec, post_chain=bool(k % 2), rgba=out[0], nu=out[1], iter=out[2])
+                        outs.append(out)
+                    for a, b in zip(*outs):
+                        assert torch.equal(a, b), (k, prec, combo, "ssaa")
     finally:
         for o in opts:
             renderer.set_option(o, 0)
