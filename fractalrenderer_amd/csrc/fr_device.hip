@@ -72,8 +72,8 @@ struct fr_ctx {
     void* coord_buf;            /* lean tile pass: W + H coordinates of the frame being rendered (prepare_kernel) */
     size_t coord_bytes;
     uint32_t tune_tile_kernel;  /* 0 = automatic (the lean tile kernel where it applies), 1 = the general tile_kernel */
-    uint32_t tune_stripes;      /* stripe shading without trap / interior style 2: 0 = automatic (lean tile pass + lane pool, kernel code
-                                   FRACTAL = 3), 1 = the effects variant of the general tile kernel */
+    uint32_t tune_stripes;      /* the Mandelbrot shader's effects (stripes, orbit trap, trap-coloured interior): 0 = automatic (lean tile
+                                   pass + lane pool, kernel code FRACTAL = 3), 1 = the effects variant of the general tile kernel */
     uint32_t tune_ssaa_band;    /* staged SSAA: samples per band of a whole frame whose sample grid is larger (0 = automatic: 2^29) */
     uint32_t tune_ssaa;         /* SSAA: 0 = automatic, 1 = the sample loop of the general tile kernel, 2 = staged (sample grid
                                  * through tile pass + lane pool, then ssaa_reduce_kernel) wherever it applies */
@@ -298,7 +298,7 @@ extern "C" int fr_ctx_set_tuning(fr_ctx* c, const char* name, int64_t value)
         if (value < 0 || value > 2) return fr_set_error(FR_ERR_INVALID_ARG, "ssaa must be 0 (automatic), 1 (sample loop of the general tile kernel) or 2 (staged)");
         c->tune_ssaa = (uint32_t)value;
     } else if (!strcmp(name, "stripes")) {
-        if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "stripes must be 0 (automatic) or 1 (the effects variant of the general tile kernel)");
+        if (value < 0 || value > 1) return fr_set_error(FR_ERR_INVALID_ARG, "stripes must be 0 (automatic) or 1 (Mandelbrot effects by the effects variant of the general tile kernel)");
         c->tune_stripes = (uint32_t)value;
     } else if (!strcmp(name, "ssaa_band_samples")) {
         if (value < 0 || value > (1ll << 30)) return fr_set_error(FR_ERR_INVALID_ARG, "ssaa_band_samples must be 0 (automatic: 2^29) or up to 2^30");

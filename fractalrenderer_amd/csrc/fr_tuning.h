@@ -33,8 +33,9 @@
  *   "ssaa"               SSAA: 0 = automatic (staged wherever the lean kernels apply; whole frames above 2^29 samples in bands, row-strip
  *                        shards above it by the sample loop),
  *                        1 = the sample loop of the general tile kernel, 2 = staged wherever it applies
- *   "stripes"            stripe shading without orbit trap / interior style 2: 0 = automatic (lean tile pass + lane pool in their
- *                        stripe instantiations), 1 = the effects variant of the general tile kernel (tests compare the two bitwise)
+ *   "stripes"            the Mandelbrot shader's effects (stripe shading, orbit trap, trap-coloured interior): 0 = automatic (lean tile
+ *                        pass + lane pool in their code-3 instantiations), 1 = the effects variant of the general tile kernel (tests
+ *                        compare the two bitwise)
  *   "ssaa_band_samples"  staged SSAA of a whole frame: sample grids larger than this go through the scratch in bands of whole
  *                        sub-tile rows (0 = automatic: 2^29 samples; tests set it small to band small frames)
  *   "debug_prologue_epoch" tests only: sets the context's prologue epoch (28 bits), to walk it across its wrap
