@@ -243,11 +243,12 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                   retired less than an eighth of their records by closed cycles -- a Julia dust -- renders its next 14
  *                   frames of the same kind without looking, then looks once more (no synchronisation: the verdict of a
  *                   frame travels with the next frame's first launch); 1 / N: always look.
- *                   Not in the effects variants or Deep_Zoom.  bench.py's headline switches it OFF so that its roofline
+ *                   Not where a sample's final z is read (stripe shading), in the Burning Ship's effects variants or Deep_Zoom.  bench.py's headline switches it OFF so that its roofline
  *                   is quoted on the reference's iteration count.
  *   "staging"       0 = automatic, 1 = single pass (every sample runs to max_iter in the tile kernel), 3 = tile pass for
  *                   the first b0 iterations + ONE lane-pool pass over the compacted survivors, whatever max_iter is.
- *                   Automatic: 3 where it applies (no SSAA, no trap / stripe effects) and pays off -- a Julia set from
+ *                   Automatic: 3 where it applies (not with the Burning Ship's trap / stripe effects; a supersampled frame's
+ *                   sample grid is rendered as a frame of its own and takes the same choice) and pays off -- a Julia set from
  *                   max_iterations 256, fp64 from 512 (384 on frames above 2^23 pixels), fp32 from 768 (512)
  *                   (profiles/r04_staging_crossover.txt).
  *   "shards"        8 or 64: shards of the work queue (each has ONE head word that its waves update with returning
