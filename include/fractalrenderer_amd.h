@@ -254,9 +254,10 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *   "shards"        8 or 64: shards of the work queue (each has ONE head word that its waves update with returning
  *                   atomics, ~15 ns apart).  Automatic: 64 (8 per XCD) for launches whose waves stop at their home shards
  *                   on grids of >= 512 workgroups, else 8.
- *   "tile_kernel"   1 = the general tile kernel; 0 = automatic: the LEAN tile kernel (coordinate tables written by a small
- *                   launch in front of the render, two 8x8 sub-tiles per wave and trip) for every one-sample render
- *                   without effects whose row strips, if sharded, are whole sub-tile rows.
+ *   "tile_kernel"   1 = the general tile kernel; 0 = automatic: the LEAN tile kernel (coordinate tables written by its own
+ *                   first workgroups -- by a small launch in front of it on capturing streams --, two 8x8 sub-tiles per wave
+ *                   and trip) for every one-sample render (the Burning Ship's trap / stripe effects excepted) whose row
+ *                   strips, if sharded, are whole sub-tile rows.
  *   "timing"        1 = record a HIP event pair around every render (fr_ctx_last_kernel_ms, fr_node_last_kernel_ms); 0 = off, the
  *                   default since 1.1.
  *   "diag_buffer"   device pointer to 4 x uint64 per wave (t_start, t_end in 100 MHz ticks, items processed, dequeues);
