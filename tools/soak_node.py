@@ -23,8 +23,10 @@ for t in range(trials):
     kw = dict(max_iterations=int(rng.choice([40, 129, 300, 1024, 2500])), center_x=-0.74 + zoom * float(rng.uniform(-0.3, 0.3)),
               center_y=0.13 + zoom * float(rng.uniform(-0.3, 0.3)), zoom=zoom, palette_mode=int(rng.integers(0, 4)),
               antialiasing_samples=int(rng.choice([1, 1, 1, 2])))
-    if ft == fr.FractalType.Mandelbrot and rng.random() < 0.2:
-        kw["orbit_trap_enabled"] = True
+    if ft == fr.FractalType.Mandelbrot and rng.random() < 0.35:       # the shader's effects: the lean kernels' code-3 instantiations
+        kw["orbit_trap_enabled"] = bool(rng.integers(0, 2))
+        kw["stripe_enabled"] = bool(rng.integers(0, 2)) or not kw["orbit_trap_enabled"]
+        kw["interior_style"] = int(rng.choice([0, 0, 1, 2]))
     if ft == fr.FractalType.Deep_Zoom:
         kw["use_perturbation"] = bool(rng.integers(0, 2)); kw["antialiasing_samples"] = 1
     nu_dt = torch.float64 if prec == fr.Precision.F64 else torch.float32
