@@ -881,11 +881,11 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      * the minimum).  Such frames take the lean tile pass and the lane pool in their code-3 instantiations instead of the
      * effects variant's lockstep run to max_iter with four running minima -- 8x8 sub-tiles, two per trip.  (Burning Ship's
      * trap and stripe sums are real accumulators: the effects variant keeps them.) */
-    const bool stripes_only = fractal == FR_FRACTAL_MANDELBROT && needs_effects(p) &&
+    const bool m_effects = fractal == FR_FRACTAL_MANDELBROT && needs_effects(p) &&
                               c->tune_stripes != 1u && c->tune_tile_kernel != 1u && (c->tune_shape == 0u || c->tune_shape == 3u) &&
                               c->tune_tile_pixels != 1u;
-    const bool stripes_lean = stripes_only && p->antialiasing_samples <= 1 && (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
-    const bool effects = needs_effects(p) && !stripes_lean;
+    const bool m_effects_lean = m_effects && p->antialiasing_samples <= 1 && (norm.nparts == 1 || norm.rows_per_strip % 8u == 0u);
+    const bool effects = needs_effects(p) && !m_effects_lean;
     const int max_iter = p->max_iterations;
 
     /* SSAA.  The sample loop of the general tile kernel runs a pixel's aa x aa samples one after the other, each to max_iter
@@ -895,7 +895,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
      * kernels' tables), rendered through tile pass + lane pool into scratch planes, and ssaa_reduce_kernel averages.  Same
      * arithmetic per sample, same summation order: bit-identical planes.  Applies where the lean kernels do (no effects,
      * 8x8 sub-tiles, strips of whole sub-tile rows in sample space) and the sample grid is a legal frame (< 2^31 samples). */
-    if (ssaa_of <= 1 && p->antialiasing_samples > 1 && (!needs_effects(p) || stripes_only) && c->tune_ssaa != 1u) {   /* (striped sample
+    if (ssaa_of <= 1 && p->antialiasing_samples > 1 && (!needs_effects(p) || m_effects) && c->tune_ssaa != 1u) {   /* (striped sample
                                                                   grids too: their samples take the stripe instantiations) */
         const uint32_t aa = (uint32_t)p->antialiasing_samples;
         const uint64_t nsamples = (uint64_t)W * aa * (uint64_t)H * aa;
@@ -975,7 +975,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     c->last_pool_closing = -1;
     /* does this render's lane pool look for cycles?  (fr_ctx_reserve sizes for the pool that looks: the shorter tile pass
      * leaves more survivors.) */
-    const bool pool_looks = staged && !stripes_lean &&           /* (a closed cycle has no z after max_iter updates) */
+    const bool pool_looks = staged && !m_effects_lean &&           /* (a closed cycle has no z after max_iter updates) */
                             (reserve_only ? c->tune_periodicity >= 0 : pool_wants_cycle_closing(c, p, W, rows_local));
     if (staged && !pool_looks) nstage = plan_stages(c, p, effects, (size_t)rows_local * W, true, bounds);   /* (still two passes) */
     /* survivor-stream writers move to the next region after every block: the regions come out equally
@@ -1102,8 +1102,8 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
     } else {
         /* a pass that runs its samples to max_iter closes cycles in escape_run: SSAA (any shape; always compiled in) and
          * the one-sample kernel with 8x8 sub-tiles (its PERIOD instantiation, launch_tile) */
-        a.period_window = !staged && !stripes_lean ? period_window(c) : 0u;   /* a staged tile pass hands its survivors on */
-        if (lean && stripes_lean)
+        a.period_window = !staged && !m_effects_lean ? period_window(c) : 0u;   /* a staged tile pass hands its survivors on */
+        if (lean && m_effects_lean)
             e = f64 ? launch_tile_lean_stripes<double>(dim3(grid), stream, a) : launch_tile_lean_stripes<float>(dim3(grid), stream, a);
         else if (lean)
             e = by_variant(fractal, f64, [&](auto t, auto f) {
@@ -1150,7 +1150,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         a.period_window = pool_looks ? period_window(c) : 0u;
         c->last_pool_closing = a.period_window != 0u;
         a.closed_flag = c->d_ctrl + kFeedbackWord;
-        if (stripes_lean)
+        if (m_effects_lean)
             e = f64 ? launch_pool_stripes<double>(dim3(sgrid), stream, a) : launch_pool_stripes<float>(dim3(sgrid), stream, a);
         else
             e = by_variant(fractal, f64, [&](auto t, auto f) {
