@@ -414,7 +414,7 @@ static hipError_t launch_tile_lean(int np, dim3 grid, hipStream_t s, const Launc
     return hipGetLastError();
 }
 
-/* stripe shading through the lean kernels (kernel code FRACTAL = 3, shade_stripes): two sub-tiles per trip, no cycle closing */
+/* the Mandelbrot shader's effects through the lean kernels (kernel code FRACTAL = 3, shade_stripes): two sub-tiles per trip, no cycle closing */
 template <typename T>
 static hipError_t launch_tile_lean_stripes(dim3 grid, hipStream_t s, const LaunchArgs& a)
 {
@@ -912,7 +912,7 @@ static int enqueue_render(fr_ctx* c, const fr_params* p, uint32_t W, uint32_t H,
         /* A WHOLE frame whose sample grid is larger (a print export: 8192^2 at aa 3 is 6e8 samples, 46 GB of sample planes and
          * survivor stream) goes through the same scratch band by band: contiguous bands of whole sub-tile rows, each rendered as
          * the one strip of "part b of B" straight into the caller's planes (FR_LAYOUT_FRAME addressing), one after the other on
-         * the stream.  Same samples, same sums: bit-identical (test_staged_ssaa_in_bands...).  Row-strip shards keep the sample
+         * the stream.  Same samples, same sums: bit-identical (test_staged_ssaa_is_bit_identical_to_the_sample_loop).  Row-strip shards keep the sample
          * loop above the cap: a band of a shard is not a shard. */
         if (lean_ok && !fits && norm.nparts == 1 && !out_frame && (uint64_t)W * aa * 8u * aa <= band_cap) {
             const uint64_t per_row = (uint64_t)W * aa * aa;                     /* samples per pixel row */
