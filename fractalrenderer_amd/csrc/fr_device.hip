@@ -728,7 +728,9 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
      * (and 64 block counters of the survivor stream) instead of 8 take the same claims at 8x the rate (kMaxShards);
      * launches with unlimited stealing keep 8: a wave probes every shard before it exits. */
     const bool limited = (bounded || moderate) && grid >= 64u;
-    uint32_t ns = (limited && grid >= 512u && tq.n_blk >= 8u * (uint32_t)kMaxShards) ? (uint32_t)kMaxShards : (uint32_t)kShards;
+    /* (from 4 blocks per shard and 256 workgroups: a 512^2 frame -- 256 blocks -- measured -6 % with 64 shards, end of round 4;
+     * the rule had asked for 8 blocks per shard and 512 workgroups) */
+    uint32_t ns = (limited && grid >= 256u && tq.n_blk >= 4u * (uint32_t)kMaxShards) ? (uint32_t)kMaxShards : (uint32_t)kShards;
     if (c->tune_shards) ns = c->tune_shards;
     tq.ns_log2 = ns == (uint32_t)kMaxShards ? 6u : 3u;
     const uint32_t waves_per_shard = (grid * 4u + ns - 1) / ns;

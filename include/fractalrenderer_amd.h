@@ -253,7 +253,7 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                   (profiles/r04_staging_crossover.txt).
  *   "shards"        8 or 64: shards of the work queue (each has ONE head word that its waves update with returning
  *                   atomics, ~15 ns apart).  Automatic: 64 (8 per XCD) for launches whose waves stop at their home shards
- *                   on grids of >= 512 workgroups, else 8.
+ *                   on grids of >= 256 workgroups over frames of >= 4096 sub-tiles, else 8.
  *   "tile_kernel"   1 = the general tile kernel; 0 = automatic: the LEAN tile kernel (coordinate tables written by its own
  *                   first workgroups -- by a small launch in front of it on capturing streams --, two 8x8 sub-tiles per wave
  *                   and trip) for every one-sample render (the Burning Ship's trap / stripe effects excepted) whose row
