@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small frames (the default view at the reference's interactive settings: max_iter 256, fp32 and fp64) over sizes, 8 against 64
-queue shards against the automatic choice, interleaved.  usage: small_frames.py [rounds]"""
+queue shards against the automatic choice, interleaved.  usage: small_frames.py [rounds] [max_iter]"""
 import os, random, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ import fractalrenderer_amd as fr
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 21
 r = fr.Renderer(0)
 random.seed(2)
-st = fr.FractalState(max_iterations=256)
+st = fr.FractalState(max_iterations=int(sys.argv[2]) if len(sys.argv) > 2 else 256)
 for W, H in ((256, 256), (400, 300), (512, 512), (640, 480), (800, 600), (1024, 768), (1280, 720)):
     out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
     for prec in (fr.Precision.F32, fr.Precision.F64):
