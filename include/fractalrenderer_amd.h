@@ -249,8 +249,10 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                   the first b0 iterations + ONE lane-pool pass over the compacted survivors, whatever max_iter is.
  *                   Automatic: 3 where it applies (not with the Burning Ship's trap / stripe effects; a supersampled frame's
  *                   sample grid is rendered as a frame of its own and takes the same choice) and pays off -- a Julia set from
- *                   max_iterations 256, fp64 from 512 (384 on frames above 2^23 pixels), fp32 from 768 (512)
- *                   (profiles/r04_staging_crossover.txt).
+ *                   max_iterations 256, fp64 from 512 (384 on frames above 2^23 pixels), fp32 from 768 (512); frames of up
+ *                   to 2^19 pixels: fp64 from 1024 (1536 up to 2^18 pixels), fp32 from 1536 -- the second launch and the
+ *                   pool's ramp cost a small frame more than they save (profiles/r04_staging_crossover.txt,
+ *                   r04_small_frame_staging.txt).
  *   "shards"        8 or 64: shards of the work queue (each has ONE head word that its waves update with returning
  *                   atomics, ~15 ns apart).  Automatic: 64 (8 per XCD) for launches whose waves stop at their home shards
  *                   on grids of >= 256 workgroups over frames of >= 4096 sub-tiles, else 8.

