@@ -779,11 +779,12 @@ static QueueArgs plan_tile_queue(const fr_ctx* c, uint32_t W, uint32_t rows_loca
 static int staging_threshold(const fr_params* p, size_t npx)
 {
     const bool big = npx > ((size_t)1 << 23);
-    if (p->fractal_type == FR_FRACTAL_JULIA) return 256;
+    if (p->fractal_type == FR_FRACTAL_JULIA) return npx <= ((size_t)1 << 20) ? 512 : 256;   /* (small frames: 256^2 ... 1024x768 at 256, the
+                                                                                              * dust 55 -> 36 us in one pass, a filled set 50 -> 23) */
     /* Small frames (end of round 4, profiles/r04_small_frame_staging.txt): the second launch and the lane pool's ramp and
      * run-out are ~45-60 us whatever the frame, which a frame of half a megapixel does not win back before max_iter 1024-2048
      * (256^2 at 512, fp64: 74 -> 49 us in one pass; 512^2 at 1024, fp32: 92 -> 72; but the Seahorse view at 2048: 129 against
-     * 168-190 in one pass): up to 2^19 pixels fp32 stages from 1536, fp64 from 1024 -- from 1536 up to 2^18 pixels. */
+     * 168-190 in one pass): up to 2^19 pixels fp32 stages from 1536, fp64 from 1024 -- from 1536 up to 2^18 pixels; a Julia set from 512 up to 2^20 pixels. */
     if (npx <= ((size_t)1 << 19)) return p->precision == FR_PRECISION_F64 ? (npx <= ((size_t)1 << 18) ? 1536 : 1024) : 1536;
     return p->precision == FR_PRECISION_F64 ? (big ? 384 : 512) : (big ? 512 : 768);
 }

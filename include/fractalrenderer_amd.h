@@ -250,7 +250,8 @@ float fr_ctx_last_kernel_ms(fr_ctx* ctx);
  *                   Automatic: 3 where it applies (not with the Burning Ship's trap / stripe effects; a supersampled frame's
  *                   sample grid is rendered as a frame of its own and takes the same choice) and pays off -- a Julia set from
  *                   max_iterations 256, fp64 from 512 (384 on frames above 2^23 pixels), fp32 from 768 (512); frames of up
- *                   to 2^19 pixels: fp64 from 1024 (1536 up to 2^18 pixels), fp32 from 1536 -- the second launch and the
+ *                   to 2^19 pixels: fp64 from 1024 (1536 up to 2^18 pixels), fp32 from 1536, a Julia set of up to 2^20 pixels
+ *                   from 512 -- the second launch and the
  *                   pool's ramp cost a small frame more than they save (profiles/r04_staging_crossover.txt,
  *                   r04_small_frame_staging.txt).
  *   "shards"        8 or 64: shards of the work queue (each has ONE head word that its waves update with returning
